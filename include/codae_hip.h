@@ -1,0 +1,200 @@
+/*
+ * codae_hip.h — C ABI of libcodae_hip.so: the MI355X (gfx950) implementation of
+ * CODAE's denoising-autoencoder training hot path.
+ *
+ * The reference (victordeleau/MUI-DeepAutoEncoder) is pure Python on PyTorch and
+ * has no FFI of its own; the boundary this library sits behind is the Python
+ * class surface of `codae.model` / `codae.tool` as used by
+ * script/train_dae_on_embedding.py and script/train_dae_on_abalone.py
+ * (SURVEY.md section 8b).  Each entry point below names the reference lines it
+ * replaces.  The host-side mirror (mui-deepautoencoder_amd/codae, ctypes) is the
+ * only caller; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain C, no torch types: device pointers + sizes; `stream` is a hipStream_t
+ *     passed as void* (torch.cuda.current_stream().cuda_stream).
+ *   - every function returns 0 on success or a negative CODAE_E_* code and never
+ *     throws; codae_last_error() returns a thread-local message.
+ *   - no function synchronises the device or allocates device memory: all
+ *     buffers (parameters, gradients, Adam state, bf16 shadows, activation
+ *     workspace, scalars) are caller-allocated and borrowed for the call.
+ *   - a handle is used by one host thread at a time (one process per GPU).
+ *   - all matrices are row-major; Linear weights are W[out][in] fp32 as in
+ *     torch.nn.Linear (embedding_denoising_autoencoder.py:63).
+ */
+#ifndef CODAE_HIP_H
+#define CODAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CODAE_ABI_VERSION 1
+
+enum {
+    CODAE_OK = 0,
+    CODAE_E_INVALID = -1,   /* bad argument / shape the kernels cannot take */
+    CODAE_E_HIP = -2,       /* a HIP runtime call or launch failed */
+    CODAE_E_UNSUPPORTED = -3
+};
+
+/* arithmetic of the GEMM chain */
+enum {
+    CODAE_PREC_F32 = 0,  /* parity mode: fp32 operands, v_mfma_f32_32x32x2_f32 (exact fp32 fma chain) */
+    CODAE_PREC_BF16 = 1  /* throughput mode: bf16 operands, fp32 accumulate, v_mfma_f32_16x16x32_bf16 */
+};
+
+typedef struct codae_engine* codae_handle;
+
+/* Network description: the Linear stack built by
+ * EmbeddingDenoisingAutoencoder.__init__ (embedding_denoising_autoencoder.py:49-129)
+ * or MixedVariableDenoisingAutoencoder.__init__ (mixed_variable_...py:45-125). */
+typedef struct {
+    int32_t n_layers;
+    const int32_t* in_features;  /* [n_layers] */
+    const int32_t* out_features; /* [n_layers] */
+    const uint8_t* relu;         /* [n_layers] 1 = ReLU follows this Linear */
+    int32_t max_batch;           /* rows the workspaces are sized for */
+    int32_t precision;           /* CODAE_PREC_* */
+} codae_spec;
+
+/* Byte sizes / element offsets the caller needs to allocate the borrowed buffers. */
+typedef struct {
+    int64_t n_param;        /* elements of the flat fp32 parameter vector (with padding) */
+    int64_t n_weight;       /* elements of the flat bf16 weight shadow (BF16 mode, else 0) */
+    int64_t act_bytes;      /* activation workspace */
+    int64_t dact_bytes;     /* activation-gradient workspace (two ping-pong buffers) */
+    int64_t slab_bytes;     /* split-K partial slabs for the weight-gradient GEMM (BF16 mode) */
+    int32_t n_scalars;      /* doubles in the scalar block (CODAE_S_*) */
+} codae_sizes;
+
+/* Borrowed device buffers. */
+typedef struct {
+    float* params;      /* flat: per layer W[out*in] then b[out], each padded to 64 floats */
+    float* grads;       /* same layout */
+    float* adam_m;      /* same layout (exp_avg)    — may be NULL if codae_step_update is unused */
+    float* adam_v;      /* same layout (exp_avg_sq) */
+    void* shadow_w;     /* bf16 copy of the weights, per layer [out][in]; BF16 mode only */
+    void* acts;         /* act_bytes */
+    void* dacts;        /* dact_bytes */
+    void* slabs;        /* slab_bytes */
+    double* scalars;    /* n_scalars doubles, see CODAE_S_* */
+} codae_buffers;
+
+/* indices into codae_buffers.scalars (device memory, accumulated across calls until zeroed) */
+enum {
+    CODAE_S_SQ_FULL = 0,     /* sum (x-y)^2              (train_dae_on_embedding.py:218-220) */
+    CODAE_S_SQ_PARTIAL = 1,  /* sum (1-fmask)(x-y)^2     (train_dae_on_embedding.py:223)     */
+    CODAE_S_GRAD_SQ = 2,     /* sum g^2 of the last codae_step_update (pre-clip)             */
+    CODAE_S_LAST_LOSS = 3,   /* mean MSE of the last step (train_dae_on_embedding.py:206)    */
+    CODAE_S_STEP_SQ = 4,     /* scratch: sum (x-y)^2 of the current step                     */
+    CODAE_S_COUNT = 8
+};
+
+/* One minibatch of the hot loop (train_dae_on_embedding.py:194-203). */
+typedef struct {
+    const float* data;       /* dataset matrix [n_rows][io] fp32 resident in HBM
+                                (ConcatenatedEmbeddingDataset.data, concatenated_embedding_dataset.py:53-74) */
+    const int32_t* row_idx;  /* [B] rows of `data` forming the batch (DataLoader+collate_embedding,
+                                data_tool.py:96-103); NULL = rows 0..B-1 */
+    const int32_t* mask_id;  /* [B] row of mask_table per sample = Corrupter.mask_to_use[idx][run]
+                                (data_tool.py:252-260); NULL = no corruption */
+    const uint8_t* mask_table; /* [n_masks][io] 0/1 = Corrupter.binary_masks (data_tool.py:202-209) */
+    int32_t B;
+    int32_t io;
+} codae_batch;
+
+typedef struct {
+    float lr, weight_decay, beta1, beta2, eps; /* torch.optim.Adam (train_dae_on_embedding.py:160-163) */
+    float max_grad_norm;   /* clip_grad_norm_(params, 1) (:213); <= 0 disables clipping */
+    int32_t step;          /* 1-based Adam step index t */
+    float loss_scale_rows; /* rows of the GLOBAL batch (data-parallel: sum over ranks); 0 = batch.B */
+} codae_hyper;
+
+const char* codae_last_error(void);
+int codae_abi_version(void);
+
+/* ---- handle ------------------------------------------------------------- */
+int codae_create(const codae_spec* spec, codae_handle* out);
+int codae_destroy(codae_handle h);
+int codae_get_sizes(codae_handle h, codae_sizes* out);
+/* element offset of layer l's weight / bias inside the flat parameter vector,
+ * and of its bf16 shadow inside shadow_w */
+int codae_param_offsets(codae_handle h, int32_t layer, int64_t* w_off, int64_t* b_off, int64_t* shadow_off);
+
+/* ---- drop-in path: model(c_input) / loss.backward() ---------------------- */
+/* forward(x) = decode(encode(x)) (embedding_denoising_autoencoder.py:137-185).
+ * x [B][in0] fp32, y [B][outL] fp32.  layer_lo/layer_hi select a sub-chain
+ * [layer_lo, layer_hi) for encode()/decode().  save_for_backward != 0 keeps the
+ * activations in bufs->acts. */
+int codae_forward(codae_handle h, const codae_buffers* bufs, const float* x, float* y, int32_t B,
+                  int32_t layer_lo, int32_t layer_hi, int32_t save_for_backward, void* stream);
+/* autograd of the chain (loss.backward(), train_dae_on_embedding.py:210):
+ * dy [B][out of layer_hi-1] fp32 -> bufs->grads of layers [layer_lo, layer_hi) (overwritten),
+ * optional dx [B][in of layer_lo] fp32.  Uses the activations the matching codae_forward left. */
+int codae_backward(codae_handle h, const codae_buffers* bufs, const float* dy, float* dx, int32_t B,
+                   int32_t layer_lo, int32_t layer_hi, void* stream);
+/* refresh the bf16 weight shadows from bufs->params (after an external optimizer step) */
+int codae_sync_shadows(codae_handle h, const codae_buffers* bufs, void* stream);
+
+/* ---- fused training step: train_dae_on_embedding.py:198-223 --------------- */
+/* gather+corrupt -> forward -> MSE(mean) loss + dL/dy + metric sums.
+ * out_y (optional, [B][io] fp32) receives the reconstruction. */
+int codae_step_forward_loss(codae_handle h, const codae_buffers* bufs, const codae_batch* batch,
+                            const codae_hyper* hyper, float* out_y, void* stream);
+/* backward for layers layer_hi-1 ... layer_lo (descending); call with decreasing
+ * ranges to hand gradient buckets to the all-reduce as they complete. */
+int codae_step_backward(codae_handle h, const codae_buffers* bufs, int32_t B, int32_t layer_lo,
+                        int32_t layer_hi, void* stream);
+/* global grad norm -> clip -> Adam -> bf16 shadow refresh (:212-215) */
+int codae_step_update(codae_handle h, const codae_buffers* bufs, const codae_hyper* hyper, void* stream);
+/* all three, single GPU */
+int codae_train_step(codae_handle h, const codae_buffers* bufs, const codae_batch* batch,
+                     const codae_hyper* hyper, void* stream);
+/* validation body (:245-258): forward + metric sums only */
+int codae_eval_step(codae_handle h, const codae_buffers* bufs, const codae_batch* batch, float* out_y,
+                    void* stream);
+
+/* ---- stand-alone ops (also used by the drop-in classes) ------------------- */
+/* model.corrupt(input, mask) = input.clone()*mask (embedding_...py:226-239) */
+int codae_corrupt(const float* x, const float* mask, float* out, int64_t n, void* stream);
+/* Corrupter.get_masks (data_tool.py:239-262): masks[k][b][:] = table[id_b] if k_of_mask[id_b]==k+1 else 0;
+ * fmask = sum_k masks[k].  masks_out is [k_max][B][io] contiguous, fmask_out [B][io]. */
+int codae_expand_masks(const int32_t* mask_id, const uint8_t* mask_table, const int32_t* k_of_mask,
+                       int32_t B, int32_t io, int32_t k_max, float* masks_out, float* fmask_out,
+                       void* stream);
+/* MSELoss fwd+bwd + metric sums on dense tensors: dy = 2 (y-x) * inv_n; scalars as CODAE_S_*.
+ * fmask may be NULL (then SQ_PARTIAL is not touched). */
+int codae_mse_loss_fwd_bwd(const float* x, const float* y, const float* fmask, float* dy, int64_t n,
+                           float inv_n, double* scalars, void* stream);
+/* clip_grad_norm_ + Adam on flat vectors (train_dae_on_embedding.py:212-215) */
+int codae_clip_adam(float* params, float* grads, float* adam_m, float* adam_v, int64_t n,
+                    const codae_hyper* hyper, double* scalars, void* stream);
+
+/* ---- GEMM primitives (exported for kernel-level parity tests / benchmarks) - */
+/* y[M][N] = act(x[M][K] . W[N][K]^T + b[N]), fp32, exact-fp32 MFMA */
+int codae_linear_f32(const float* x, const float* W, const float* b, float* y, int32_t M, int32_t N,
+                     int32_t K, int32_t relu, void* stream);
+/* dx[M][K] = (dy[M][N] . W[N][K]) * [relu_src > 0]   (relu_src [M][K] or NULL) */
+int codae_dgrad_f32(const float* dy, const float* W, const float* relu_src, float* dx, int32_t M,
+                    int32_t N, int32_t K, void* stream);
+/* dW[N][K] = dy[M][N]^T . x[M][K] ; db[N] = colsum(dy) (db may be NULL) */
+int codae_wgrad_f32(const float* dy, const float* x, float* dW, float* db, int32_t M, int32_t N,
+                    int32_t K, void* stream);
+/* bf16 counterparts; x, W, dy, y, dx are bf16 (uint16 storage) unless noted.
+ * y_f32 != 0 -> y is fp32. */
+int codae_linear_bf16(const void* x, const void* W, const float* b, void* y, int32_t y_f32, int32_t M,
+                      int32_t N, int32_t K, int32_t relu, void* stream);
+int codae_dgrad_bf16(const void* dy, const void* W, const void* relu_src, void* dx, float* db_prev,
+                     int32_t M, int32_t N, int32_t K, void* stream);
+int codae_wgrad_bf16(const void* dy, const void* x, float* dW, void* slabs, int64_t slab_bytes,
+                     int32_t M, int32_t N, int32_t K, void* stream);
+int codae_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CODAE_HIP_H */

@@ -1,0 +1,156 @@
+"""Device-resident training loop for the embedding DAE: the fast counterpart of the inner loop of
+script/train_dae_on_embedding.py:194-223 (reference), one fused HIP step per minibatch.
+
+What differs from the drop-in path (model(c_input) + torch loss/optimizer):
+  - the dataset matrix stays in HBM and a batch is a vector of int32 row indices
+    (DataLoader + collate_embedding, data_tool.py:96-103, become a gather inside the kernels);
+  - the corruption mask is a per-sample mask id (Corrupter.mask_to_use[idx][run]) plus the small
+    uint8 table, applied on load; the [B, io] fp32 fmask is never built;
+  - loss, dL/dy, the epoch metrics (ftl / ptl sums), grad-norm clip and Adam are kernels of
+    libcodae_hip.so; nothing is copied to the host per step (the reference moves a [B, io] fp32
+    tensor to the host every step, :218-223).
+
+Data parallel (one process per GPU, torch.distributed; backend "nccl" is RCCL over xGMI):
+the minibatch is sharded by rows, parameters and Adam state are replicated, the loss is scaled
+by the GLOBAL batch so that a SUM all-reduce of the gradients gives the global-batch mean
+gradient; gradients are reduced in layer buckets, each launched as soon as its layers'
+backward kernels are enqueued, so the reduction of late layers overlaps the backward GEMMs of
+early ones; clip + Adam then run identically on every rank.
+"""
+import torch
+
+
+def default_buckets(n_layers, n_buckets=4):
+    """[(lo, hi)] layer ranges in backward order, e.g. 10 layers -> (7,10) (5,7) (2,5) (0,2)."""
+    n_buckets = max(1, min(n_buckets, n_layers))
+    edges = [round(n_layers * i / n_buckets) for i in range(n_buckets + 1)]
+    return [(edges[i], edges[i + 1]) for i in range(n_buckets - 1, -1, -1) if edges[i] < edges[i + 1]]
+
+
+class DataParallel:
+    """Bucketed gradient all-reduce around an engine's step_* phases.
+
+    `engine` needs: L, grads (flat tensor), w_off (list), b_off (list), n_param,
+    step_forward_loss(batch, hyper), step_backward(B, lo, hi), step_update(hyper).
+    """
+
+    def __init__(self, engine, process_group=None, n_buckets=4):
+        import torch.distributed as dist
+        self.dist = dist
+        self.engine = engine
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.buckets = default_buckets(engine.L, n_buckets)
+
+    def _weight_span(self, lo, hi):
+        # weights of consecutive layers are contiguous in the flat vector
+        end = self.engine.w_off[hi] if hi < self.engine.L else self.engine.b_off[0]
+        return self.engine.grads[self.engine.w_off[lo]:end]
+
+    def backward_and_reduce(self, B):
+        eng = self.engine
+        if self.world == 1:
+            eng.step_backward(B, 0, eng.L)
+            return
+        works = []
+        for lo, hi in self.buckets:
+            eng.step_backward(B, lo, hi)
+            works.append(self.dist.all_reduce(self._weight_span(lo, hi), op=self.dist.ReduceOp.SUM,
+                                              group=self.group, async_op=True))
+        # bias gradients of layer l are finished by the dgrad of layer l+1: reduce the block last
+        works.append(self.dist.all_reduce(eng.grads[eng.b_off[0]:eng.n_param], op=self.dist.ReduceOp.SUM,
+                                          group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+
+    def broadcast_params(self, params_flat):
+        if self.world > 1:
+            self.dist.broadcast(params_flat, src=0, group=self.group)
+
+    def reduce_scalars(self, t):
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t
+
+
+class HipEmbeddingTrainer:
+    """Owns a DaeEngine, the resident dataset and the mask tables; runs train / eval steps."""
+
+    def __init__(self, schedule, data, mask_table_u8, mask_to_use_i32, lr, weight_decay, clip=1.0,
+                 max_batch=8192, precision="bf16", device="cuda:0", distributed=False, n_buckets=4):
+        from .hip.engine import DaeEngine
+        self.device = torch.device(device)
+        self.engine = DaeEngine(schedule, max_batch, precision, self.device)
+        self.data = data.to(device=self.device, dtype=torch.float32).contiguous()
+        self.mask_table = None if mask_table_u8 is None else mask_table_u8.to(self.device).contiguous()
+        self.mask_to_use = None if mask_to_use_i32 is None else mask_to_use_i32.to(self.device).contiguous()
+        self.lr, self.weight_decay, self.clip = lr, weight_decay, clip
+        self.dp = DataParallel(self.engine, n_buckets=n_buckets) if distributed else None
+        self.world = self.dp.world if self.dp else 1
+
+    # ---- parameters ---------------------------------------------------------------------
+    def load_params(self, params):
+        self.engine.load_params(params)
+        if self.dp:
+            self.dp.broadcast_params(self.engine.params)
+            self.engine.sync_shadows()
+
+    def init_params(self, seed=0):
+        """Xavier-uniform weights / zero bias (embedding_...py:188-211), same on every rank."""
+        g = torch.Generator(device="cpu")
+        g.manual_seed(seed)
+        ps = []
+        for (k, n, _) in self.engine.schedule:
+            a = (6.0 / (k + n)) ** 0.5
+            ps.append(((torch.rand((n, k), generator=g) * 2 - 1) * a, torch.zeros(n)))
+        self.load_params(ps)
+
+    def params(self):
+        return [(self.engine.weight(l), self.engine.bias(l)) for l in range(self.engine.L)]
+
+    # ---- steps ---------------------------------------------------------------------------
+    def _batch(self, row_idx, run):
+        mask_id = None
+        if self.mask_to_use is not None and run is not None:
+            mask_id = self.mask_to_use[row_idx.long(), run].contiguous()
+        return self.engine.make_batch(self.data, row_idx, mask_id, self.mask_table)
+
+    def train_batch(self, row_idx, run=0, mask_id=None):
+        """One optimizer step on rows `row_idx` (int32 device tensor) of the resident dataset."""
+        eng = self.engine
+        if mask_id is None:
+            batch = self._batch(row_idx, run)
+        else:
+            batch = eng.make_batch(self.data, row_idx, mask_id, self.mask_table)
+        B = batch.B
+        hyper = eng.hyper(self.lr, self.weight_decay, self.clip, global_rows=B * self.world)
+        if self.dp is None:
+            eng.train_step(batch, hyper)
+        else:
+            eng.step_forward_loss(batch, hyper)
+            self.dp.backward_and_reduce(B)
+            eng.step_update(hyper)
+        self._keep = batch  # keep the ctypes struct (and its tensors) alive until the next call
+        return B
+
+    def eval_batch(self, row_idx, run=0, want_y=False):
+        batch = self._batch(row_idx, run)
+        y = (torch.empty((batch.B, self.data.shape[1]), dtype=torch.float32, device=self.device)
+             if want_y else None)
+        self.engine.eval_step(batch, y)
+        self._keep = batch
+        return y
+
+    def epoch_sums(self, reset=True):
+        """(sum (x-y)^2, sum (1-fmask)(x-y)^2) accumulated since the last reset, over all ranks."""
+        s = self.engine.scalars[:2].clone()
+        if self.dp:
+            self.dp.reduce_scalars(s)
+        if reset:
+            self.engine.zero_metric_sums()
+        s = s.cpu()
+        return float(s[0]), float(s[1])
+
+    def last_loss_and_grad_norm(self):
+        _, _, gsq, loss = self.engine.read_scalars()
+        return loss, gsq ** 0.5

@@ -1,0 +1,109 @@
+// Shared declarations for libcodae_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "codae_hip.h"
+
+namespace codae {
+
+void set_error(const char* fmt, ...);
+
+#define CODAE_HIP_CHECK(expr)                                                              \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            codae::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return CODAE_E_HIP;                                                            \
+        }                                                                                  \
+    } while (0)
+
+#define CODAE_LAUNCH_CHECK()                                                               \
+    do {                                                                                   \
+        hipError_t e_ = hipGetLastError();                                                 \
+        if (e_ != hipSuccess) {                                                            \
+            codae::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+            return CODAE_E_HIP;                                                            \
+        }                                                                                  \
+    } while (0)
+
+#define CODAE_REQUIRE(cond, ...)                                                           \
+    do {                                                                                   \
+        if (!(cond)) {                                                                     \
+            codae::set_error(__VA_ARGS__);                                                 \
+            return CODAE_E_INVALID;                                                        \
+        }                                                                                  \
+    } while (0)
+
+typedef uint16_t bf16_t;  // raw bf16 storage
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even through the hardware convert (keeps NaN a NaN)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---- generic exact-fp32 GEMM (gemm_f32.hip) --------------------------------
+// C[i][j] = epilogue( sum_k A(i,k) * B(j,k) ), A(i,k) = A[i*a_rs + k*a_ks], B(j,k) = B[j*b_rs + k*b_ks]
+struct GemmF32 {
+    const float* A; int64_t a_rs, a_ks;
+    const float* B; int64_t b_rs, b_ks;
+    float* C; int64_t ldc;
+    int M, N, K;
+    const float* bias;       // [N] added before activation, or null
+    int relu;                // max(v, 0)
+    const float* relu_src;   // [M][ld_relu] multiply by (src > 0), or null
+    int64_t ld_relu;
+    float* colsum;           // [N] atomicAdd of column sums of the stored values, or null
+};
+int gemm_f32(const GemmF32& g, hipStream_t s);
+
+// ---- bf16 MFMA GEMM (gemm_bf16.hip) ----------------------------------------
+enum { OP_KC = 0,  // operand stored [rows][k] (k contiguous)
+       OP_KS = 1   // operand stored [k][rows] (rows contiguous; transposed LDS reads)
+};
+struct GemmBf16 {
+    const bf16_t* A; int64_t lda; int a_mode;   // output row index i
+    const bf16_t* B; int64_t ldb; int b_mode;   // output col index j
+    void* C; int64_t ldc; int c_f32;            // bf16 or fp32 output [M][N]
+    int M, N, K;
+    const float* bias;
+    int relu;
+    const bf16_t* relu_src; int64_t ld_relu;
+    float* colsum;
+    int split_k;             // >1: fp32 partial slabs C + z*M*ldc, K range split evenly in BK units
+};
+bool gemm_bf16_supported(int M, int N, int K);
+int gemm_bf16(const GemmBf16& g, hipStream_t s);
+
+// ---- elementwise / reductions (elementwise.hip) ----------------------------
+int launch_gather_corrupt(const codae_batch* b, void* out, int out_bf16, hipStream_t s);
+int launch_cast_bf16(const float* src, bf16_t* dst, int64_t n, hipStream_t s);
+int launch_corrupt(const float* x, const float* mask, float* out, int64_t n, hipStream_t s);
+int launch_expand_masks(const int32_t* mask_id, const uint8_t* table, const int32_t* k_of_mask, int B, int io,
+                        int k_max, float* masks_out, float* fmask_out, hipStream_t s);
+// y fp32 [B][io]; x gathered from batch; writes dy (fp32 or bf16), metric sums, optional colsum (bias grad)
+int launch_mse_loss(const codae_batch* b, const float* y, void* dy, int dy_bf16, float inv_n, float* colsum,
+                    double* scalars, int want_grad, hipStream_t s);
+int launch_mse_dense(const float* x, const float* y, const float* fmask, float* dy, int64_t n, float inv_n,
+                     double* scalars, hipStream_t s);
+int launch_sumsq(const float* g, int64_t n, double* out, hipStream_t s);
+int launch_clip_adam(float* p, float* g, float* m, float* v, int64_t n, const codae_hyper* hp,
+                     const double* grad_sq, bf16_t* shadow, const int64_t* shadow_map, hipStream_t s);
+int launch_reduce_slabs(const float* slabs, int n_slabs, int64_t slab_stride, float* out, int64_t n, hipStream_t s);
+int launch_finish_loss(double* scalars, double inv_n, hipStream_t s);
+int launch_cast_f32(const bf16_t* src, float* dst, int64_t n, hipStream_t s);
+// out[n] += sum_m src[m][n]
+int launch_colsum_f32(const float* src, int M, int N, float* out, hipStream_t s);
+
+}  // namespace codae

@@ -1,0 +1,450 @@
+// HBM-bound pieces of the DAE step: batch gather + slot corruption, mask expansion,
+// fused MSE loss forward/backward with the reference's per-step metrics, gradient norm,
+// clip + Adam with bf16 shadow refresh.  All are single-pass, 16 B per lane where the
+// row width allows, grid capped at 2048 blocks with a grid-stride loop.
+#include "codae_common.h"
+
+namespace codae {
+namespace {
+
+constexpr int NT = 256;
+
+inline int grid_for(int64_t work_items) {
+    int64_t b = (work_items + NT - 1) / NT;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// sum over the 256-thread block; result valid in thread 0
+__device__ __forceinline__ float block_sum(float v, float* red /*[4]*/) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0) r = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d) {
+    uint2 o;
+    o.x = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+    o.y = (uint32_t)f32_to_bf16(c) | ((uint32_t)f32_to_bf16(d) << 16);
+    return o;
+}
+
+// ---- a2 + a10: out[b][:] = data[row_idx[b]][:] * mask_table[mask_id[b]][:] -----------------
+// (collate_embedding data_tool.py:96-103 + corrupt embedding_...py:226-239 fused; the [B,io]
+// fp32 mask of Corrupter.get_masks is never materialised.)
+template <bool VEC, bool OUT_BF16>
+__global__ __launch_bounds__(NT) void gather_corrupt_kernel(const float* __restrict__ data,
+                                                            const int32_t* __restrict__ row_idx,
+                                                            const int32_t* __restrict__ mask_id,
+                                                            const uint8_t* __restrict__ table, int B, int io,
+                                                            void* __restrict__ out) {
+    constexpr int W = VEC ? 4 : 1;
+    const int cols = io / W;
+    const int64_t total = (int64_t)B * cols;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < total; e += (int64_t)gridDim.x * NT) {
+        const int b = (int)(e / cols);
+        const int c = (int)(e - (int64_t)b * cols) * W;
+        const int64_t src_row = row_idx ? row_idx[b] : b;
+        const float* src = data + src_row * io + c;
+        float v[4];
+        if constexpr (VEC) {
+            const float4 x = *reinterpret_cast<const float4*>(src);
+            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+            if (mask_id) {
+                const uint32_t m = *reinterpret_cast<const uint32_t*>(table + (int64_t)mask_id[b] * io + c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = ((m >> (8 * k)) & 0xff) ? v[k] : 0.f;
+            }
+        } else {
+            v[0] = src[0];
+            if (mask_id) v[0] = table[(int64_t)mask_id[b] * io + c] ? v[0] : 0.f;
+        }
+        const int64_t o = (int64_t)b * io + c;
+        if constexpr (OUT_BF16) {
+            bf16_t* op = reinterpret_cast<bf16_t*>(out) + o;
+            if constexpr (VEC) *reinterpret_cast<uint2*>(op) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+            else op[0] = f32_to_bf16(v[0]);
+        } else {
+            float* op = reinterpret_cast<float*>(out) + o;
+            if constexpr (VEC) *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+            else op[0] = v[0];
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                       int64_t n) {
+    const int64_t n4 = n / 4;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < n4; e += (int64_t)gridDim.x * NT) {
+        const float4 x = reinterpret_cast<const float4*>(src)[e];
+        reinterpret_cast<uint2*>(dst)[e] = pack_bf16x4(x.x, x.y, x.z, x.w);
+    }
+    for (int64_t e = n4 * 4 + (int64_t)blockIdx.x * NT + threadIdx.x; e < n; e += (int64_t)gridDim.x * NT)
+        dst[e] = f32_to_bf16(src[e]);
+}
+
+__global__ __launch_bounds__(NT) void cast_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst,
+                                                      int64_t n) {
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < n; e += (int64_t)gridDim.x * NT)
+        dst[e] = bf16_to_f32(src[e]);
+}
+
+// model.corrupt on dense tensors: out = x * mask
+__global__ __launch_bounds__(NT) void corrupt_kernel(const float* __restrict__ x, const float* __restrict__ m,
+                                                     float* __restrict__ out, int64_t n) {
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < n; e += (int64_t)gridDim.x * NT)
+        out[e] = x[e] * m[e];
+}
+
+// Corrupter.get_masks (data_tool.py:252-262)
+__global__ __launch_bounds__(NT) void expand_masks_kernel(const int32_t* __restrict__ mask_id,
+                                                          const uint8_t* __restrict__ table,
+                                                          const int32_t* __restrict__ k_of_mask, int B, int io,
+                                                          int k_max, float* __restrict__ masks,
+                                                          float* __restrict__ fmask) {
+    const int64_t total = (int64_t)B * io;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < total; e += (int64_t)gridDim.x * NT) {
+        const int b = (int)(e / io);
+        const int c = (int)(e - (int64_t)b * io);
+        const int id = mask_id[b];
+        const float v = table[(int64_t)id * io + c] ? 1.f : 0.f;
+        const int k = k_of_mask[id] - 1;
+        for (int kk = 0; kk < k_max; ++kk) masks[(int64_t)kk * total + e] = (kk == k) ? v : 0.f;
+        fmask[e] = v;
+    }
+}
+
+// ---- a4 + a11: MSELoss(mean) forward/backward + the per-step metric sums --------------------
+// One block owns ROWS consecutive batch rows and sweeps all columns, so that the bias gradient
+// of the last Linear (column sums of dy) costs one atomic per column per block.
+//   dy = 2 (y - x) * inv_n                          (autograd of train_dae_on_embedding.py:206)
+//   SQ_FULL    += sum (x-y)^2                        (:218-220)
+//   SQ_PARTIAL += sum (1-fmask)(x-y)^2               (:223)
+constexpr int LOSS_ROWS = 32;
+template <bool VEC, bool DY_BF16>
+__global__ __launch_bounds__(NT) void mse_loss_kernel(const float* __restrict__ data,
+                                                      const int32_t* __restrict__ row_idx,
+                                                      const int32_t* __restrict__ mask_id,
+                                                      const uint8_t* __restrict__ table, int B, int io,
+                                                      const float* __restrict__ y, void* __restrict__ dy,
+                                                      float inv_n, float* __restrict__ colsum,
+                                                      double* __restrict__ scalars, int want_grad) {
+    __shared__ float red[4];
+    constexpr int W = VEC ? 4 : 1;
+    const int cols = io / W;
+    const int r_begin = blockIdx.x * LOSS_ROWS;
+    const int r_end = min(B, r_begin + LOSS_ROWS);
+    float sq = 0.f, sqp = 0.f;
+    for (int cv = threadIdx.x; cv < cols; cv += NT) {
+        const int c = cv * W;
+        float cs[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int b = r_begin; b < r_end; ++b) {
+            const int64_t src_row = row_idx ? row_idx[b] : b;
+            float xv[4], yv[4];
+            uint32_t m = 0x01010101u;
+            if constexpr (VEC) {
+                const float4 x4 = *reinterpret_cast<const float4*>(data + src_row * io + c);
+                const float4 y4 = *reinterpret_cast<const float4*>(y + (int64_t)b * io + c);
+                xv[0] = x4.x; xv[1] = x4.y; xv[2] = x4.z; xv[3] = x4.w;
+                yv[0] = y4.x; yv[1] = y4.y; yv[2] = y4.z; yv[3] = y4.w;
+                if (mask_id) m = *reinterpret_cast<const uint32_t*>(table + (int64_t)mask_id[b] * io + c);
+            } else {
+                xv[0] = data[src_row * io + c];
+                yv[0] = y[(int64_t)b * io + c];
+                if (mask_id) m = table[(int64_t)mask_id[b] * io + c];
+            }
+            float g[4];
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                const float d = xv[k] - yv[k];
+                const float se = d * d;
+                sq += se;
+                if (((m >> (8 * k)) & 0xff) == 0) sqp += se;
+                g[k] = -2.f * d * inv_n;
+                cs[k] += g[k];
+            }
+            if (want_grad) {
+                const int64_t o = (int64_t)b * io + c;
+                if constexpr (DY_BF16) {
+                    bf16_t* op = reinterpret_cast<bf16_t*>(dy) + o;
+                    if constexpr (VEC) *reinterpret_cast<uint2*>(op) = pack_bf16x4(g[0], g[1], g[2], g[3]);
+                    else op[0] = f32_to_bf16(g[0]);
+                } else {
+                    float* op = reinterpret_cast<float*>(dy) + o;
+                    if constexpr (VEC) *reinterpret_cast<float4*>(op) = make_float4(g[0], g[1], g[2], g[3]);
+                    else op[0] = g[0];
+                }
+            }
+        }
+        if (want_grad && colsum) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) atomicAdd(&colsum[c + k], cs[k]);
+        }
+    }
+    const float bsq = block_sum(sq, red);
+    const float bsqp = block_sum(sqp, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&scalars[CODAE_S_SQ_FULL], (double)bsq);
+        atomicAdd(&scalars[CODAE_S_STEP_SQ], (double)bsq);
+        if (mask_id) atomicAdd(&scalars[CODAE_S_SQ_PARTIAL], (double)bsqp);
+    }
+}
+
+// dense variant for the drop-in path (x, y, fmask already materialised)
+__global__ __launch_bounds__(NT) void mse_dense_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                       const float* __restrict__ fmask, float* __restrict__ dy,
+                                                       int64_t n, float inv_n, double* __restrict__ scalars) {
+    __shared__ float red[4];
+    float sq = 0.f, sqp = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < n; e += (int64_t)gridDim.x * NT) {
+        const float d = x[e] - y[e];
+        const float se = d * d;
+        sq += se;
+        if (fmask) sqp += (1.f - fmask[e]) * se;
+        if (dy) dy[e] = -2.f * d * inv_n;
+    }
+    const float bsq = block_sum(sq, red);
+    const float bsqp = block_sum(sqp, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&scalars[CODAE_S_SQ_FULL], (double)bsq);
+        atomicAdd(&scalars[CODAE_S_STEP_SQ], (double)bsq);
+        if (fmask) atomicAdd(&scalars[CODAE_S_SQ_PARTIAL], (double)bsqp);
+    }
+}
+
+// LAST_LOSS = STEP_SQ * inv_n ; reset the per-step accumulators
+__global__ void finish_loss_kernel(double* scalars, double inv_n) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        scalars[CODAE_S_LAST_LOSS] = scalars[CODAE_S_STEP_SQ] * inv_n;
+        scalars[CODAE_S_STEP_SQ] = 0.0;
+        scalars[CODAE_S_GRAD_SQ] = 0.0;
+    }
+}
+
+// ---- a7: sum g^2 (clip_grad_norm_, train_dae_on_embedding.py:213) ---------------------------
+__global__ __launch_bounds__(NT) void sumsq_kernel(const float* __restrict__ g, int64_t n, double* out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const int64_t n4 = n / 4;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < n4; e += (int64_t)gridDim.x * NT) {
+        const float4 v = reinterpret_cast<const float4*>(g)[e];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    for (int64_t e = n4 * 4 + (int64_t)blockIdx.x * NT + threadIdx.x; e < n; e += (int64_t)gridDim.x * NT)
+        s += g[e] * g[e];
+    const float b = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(out, (double)b);
+}
+
+// ---- a7 + a8: clip scale folded into Adam (torch.optim.Adam, amsgrad off, L2 decay) ----------
+struct AdamConst {
+    float lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, wd, max_norm;
+};
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float coef, const AdamConst& c) {
+    g = g * coef + c.wd * p;
+    m = c.beta1 * m + (1.f - c.beta1) * g;
+    v = c.beta2 * v + (1.f - c.beta2) * g * g;
+    const float denom = sqrtf(v) * c.inv_sqrt_bc2 + c.eps;
+    p = p - c.lr_over_bc1 * (m / denom);
+}
+
+__global__ __launch_bounds__(NT) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                       AdamConst c, const double* __restrict__ grad_sq,
+                                                       bf16_t* __restrict__ shadow) {
+    float coef = 1.f;
+    if (c.max_norm > 0.f) {
+        const float total = sqrtf((float)(*grad_sq));
+        coef = fminf(1.f, c.max_norm / (total + 1e-6f));
+    }
+    const int64_t n4 = n / 4;  // n is padded to a multiple of 64 by the engine; tail handled below anyway
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < n4; e += (int64_t)gridDim.x * NT) {
+        float4 pp = reinterpret_cast<float4*>(p)[e];
+        const float4 gg = reinterpret_cast<const float4*>(g)[e];
+        float4 mm = reinterpret_cast<float4*>(m)[e];
+        float4 vv = reinterpret_cast<float4*>(v)[e];
+        adam_one(pp.x, gg.x, mm.x, vv.x, coef, c);
+        adam_one(pp.y, gg.y, mm.y, vv.y, coef, c);
+        adam_one(pp.z, gg.z, mm.z, vv.z, coef, c);
+        adam_one(pp.w, gg.w, mm.w, vv.w, coef, c);
+        reinterpret_cast<float4*>(p)[e] = pp;
+        reinterpret_cast<float4*>(m)[e] = mm;
+        reinterpret_cast<float4*>(v)[e] = vv;
+        if (shadow) reinterpret_cast<uint2*>(shadow)[e] = pack_bf16x4(pp.x, pp.y, pp.z, pp.w);
+    }
+    for (int64_t e = n4 * 4 + (int64_t)blockIdx.x * NT + threadIdx.x; e < n; e += (int64_t)gridDim.x * NT) {
+        float pp = p[e], mm = m[e], vv = v[e];
+        adam_one(pp, g[e], mm, vv, coef, c);
+        p[e] = pp; m[e] = mm; v[e] = vv;
+        if (shadow) shadow[e] = f32_to_bf16(pp);
+    }
+}
+
+// out[i] = sum_s slabs[s][i]  (split-K partials of the weight-gradient GEMM)
+__global__ __launch_bounds__(NT) void reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs,
+                                                          int64_t stride, float* __restrict__ out, int64_t n) {
+    const int64_t n4 = n / 4;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < n4; e += (int64_t)gridDim.x * NT) {
+        float4 a = reinterpret_cast<const float4*>(slabs)[e];
+        for (int s = 1; s < n_slabs; ++s) {
+            const float4 b = reinterpret_cast<const float4*>(slabs + s * stride)[e];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        reinterpret_cast<float4*>(out)[e] = a;
+    }
+    for (int64_t e = n4 * 4 + (int64_t)blockIdx.x * NT + threadIdx.x; e < n; e += (int64_t)gridDim.x * NT) {
+        float a = slabs[e];
+        for (int s = 1; s < n_slabs; ++s) a += slabs[s * stride + e];
+        out[e] = a;
+    }
+}
+
+// out[c] += sum over the block's 64 rows of src[r][c]   (bias gradient of a dense dy)
+__global__ __launch_bounds__(NT) void colsum_f32_kernel(const float* __restrict__ src, int M, int N,
+                                                        float* __restrict__ out) {
+    const int r_begin = blockIdx.x * 64;
+    const int r_end = min(M, r_begin + 64);
+    for (int c = threadIdx.x; c < N; c += NT) {
+        float s = 0.f;
+        for (int r = r_begin; r < r_end; ++r) s += src[(int64_t)r * N + c];
+        atomicAdd(&out[c], s);
+    }
+}
+
+inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+int launch_gather_corrupt(const codae_batch* b, void* out, int out_bf16, hipStream_t s) {
+    CODAE_REQUIRE(b && b->data && out && b->B > 0 && b->io > 0, "gather_corrupt: bad batch");
+    CODAE_REQUIRE(!b->mask_id || b->mask_table, "gather_corrupt: mask_id without mask_table");
+    const bool vec = (b->io % 4 == 0) && a16(b->data) && a16(out) && (!b->mask_id || (reinterpret_cast<uintptr_t>(b->mask_table) & 3) == 0);
+    const int64_t items = (int64_t)b->B * (vec ? b->io / 4 : b->io);
+    const int grid = grid_for(items);
+#define GC(V, O) hipLaunchKernelGGL((gather_corrupt_kernel<V, O>), dim3(grid), dim3(NT), 0, s, b->data, b->row_idx, \
+                                    b->mask_id, b->mask_table, b->B, b->io, out)
+    if (vec && out_bf16) GC(true, true);
+    else if (vec) GC(true, false);
+    else if (out_bf16) GC(false, true);
+    else GC(false, false);
+#undef GC
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+int launch_cast_bf16(const float* src, bf16_t* dst, int64_t n, hipStream_t s) {
+    CODAE_REQUIRE(src && dst && n > 0 && a16(src) && (reinterpret_cast<uintptr_t>(dst) & 7) == 0, "cast: bad args");
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, s, src, dst, n);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+int launch_cast_f32(const bf16_t* src, float* dst, int64_t n, hipStream_t s) {
+    CODAE_REQUIRE(src && dst && n > 0, "cast: bad args");
+    hipLaunchKernelGGL(cast_f32_kernel, dim3(grid_for(n)), dim3(NT), 0, s, src, dst, n);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+int launch_corrupt(const float* x, const float* mask, float* out, int64_t n, hipStream_t s) {
+    CODAE_REQUIRE(x && mask && out && n > 0, "corrupt: bad args");
+    hipLaunchKernelGGL(corrupt_kernel, dim3(grid_for(n)), dim3(NT), 0, s, x, mask, out, n);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+int launch_expand_masks(const int32_t* mask_id, const uint8_t* table, const int32_t* k_of_mask, int B, int io,
+                        int k_max, float* masks_out, float* fmask_out, hipStream_t s) {
+    CODAE_REQUIRE(mask_id && table && k_of_mask && masks_out && fmask_out && B > 0 && io > 0 && k_max > 0,
+                  "expand_masks: bad args");
+    hipLaunchKernelGGL(expand_masks_kernel, dim3(grid_for((int64_t)B * io)), dim3(NT), 0, s, mask_id, table,
+                       k_of_mask, B, io, k_max, masks_out, fmask_out);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+int launch_mse_loss(const codae_batch* b, const float* y, void* dy, int dy_bf16, float inv_n, float* colsum,
+                    double* scalars, int want_grad, hipStream_t s) {
+    CODAE_REQUIRE(b && b->data && y && scalars && b->B > 0 && b->io > 0, "mse_loss: bad args");
+    CODAE_REQUIRE(!want_grad || dy, "mse_loss: gradient requested without dy");
+    const bool vec = (b->io % 4 == 0) && a16(b->data) && a16(y) && (!dy || a16(dy)) &&
+                     (!b->mask_id || (reinterpret_cast<uintptr_t>(b->mask_table) & 3) == 0);
+    const int grid = (b->B + LOSS_ROWS - 1) / LOSS_ROWS;
+#define ML(V, O) hipLaunchKernelGGL((mse_loss_kernel<V, O>), dim3(grid), dim3(NT), 0, s, b->data, b->row_idx, \
+                                    b->mask_id, b->mask_table, b->B, b->io, y, dy, inv_n, colsum, scalars, want_grad)
+    if (vec && dy_bf16) ML(true, true);
+    else if (vec) ML(true, false);
+    else if (dy_bf16) ML(false, true);
+    else ML(false, false);
+#undef ML
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+int launch_mse_dense(const float* x, const float* y, const float* fmask, float* dy, int64_t n, float inv_n,
+                     double* scalars, hipStream_t s) {
+    CODAE_REQUIRE(x && y && scalars && n > 0, "mse_dense: bad args");
+    hipLaunchKernelGGL(mse_dense_kernel, dim3(grid_for(n)), dim3(NT), 0, s, x, y, fmask, dy, n, inv_n, scalars);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+int launch_finish_loss(double* scalars, double inv_n, hipStream_t s) {
+    hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(64), 0, s, scalars, inv_n);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+int launch_sumsq(const float* g, int64_t n, double* out, hipStream_t s) {
+    CODAE_REQUIRE(g && out && n > 0 && a16(g), "sumsq: bad args");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, s, g, n, out);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+int launch_clip_adam(float* p, float* g, float* m, float* v, int64_t n, const codae_hyper* hp,
+                     const double* grad_sq, bf16_t* shadow, const int64_t*, hipStream_t s) {
+    CODAE_REQUIRE(p && g && m && v && hp && n > 0, "clip_adam: bad args");
+    CODAE_REQUIRE(a16(p) && a16(g) && a16(m) && a16(v), "clip_adam: buffers must be 16-byte aligned");
+    CODAE_REQUIRE(hp->step >= 1, "clip_adam: step must be >= 1");
+    CODAE_REQUIRE(hp->max_grad_norm <= 0.f || grad_sq, "clip_adam: clipping needs the grad_sq scalar");
+    AdamConst c;
+    const double bc1 = 1.0 - pow((double)hp->beta1, (double)hp->step);
+    const double bc2 = 1.0 - pow((double)hp->beta2, (double)hp->step);
+    c.lr_over_bc1 = (float)((double)hp->lr / bc1);
+    c.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    c.beta1 = hp->beta1; c.beta2 = hp->beta2; c.eps = hp->eps; c.wd = hp->weight_decay;
+    c.max_norm = hp->max_grad_norm;
+    hipLaunchKernelGGL(clip_adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, s, p, g, m, v, n, c, grad_sq, shadow);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+int launch_colsum_f32(const float* src, int M, int N, float* out, hipStream_t s) {
+    CODAE_REQUIRE(src && out && M > 0 && N > 0, "colsum: bad args");
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3((M + 63) / 64), dim3(NT), 0, s, src, M, N, out);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+int launch_reduce_slabs(const float* slabs, int n_slabs, int64_t stride, float* out, int64_t n, hipStream_t s) {
+    CODAE_REQUIRE(slabs && out && n_slabs >= 1 && n > 0, "reduce_slabs: bad args");
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, s, slabs, n_slabs, stride, out, n);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+}  // namespace codae

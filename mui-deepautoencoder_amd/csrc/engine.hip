@@ -1,0 +1,538 @@
+// C-ABI entry points of libcodae_hip.so and the per-model engine that chains the kernels
+// into the DAE training step (script/train_dae_on_embedding.py:198-215 of the reference).
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "codae_common.h"
+
+namespace codae {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+}  // namespace codae
+
+using namespace codae;
+
+// Flat parameter layout: [W_0 | W_1 | ... | W_{L-1} | b_0 | ... | b_{L-1}], every tensor padded to
+// a multiple of 64 floats (256 B) so each starts 16-B aligned and the whole vector can be swept
+// 16 B per lane by the norm / Adam kernels.  Padding stays zero under Adam (g = 0, p = 0).
+struct codae_engine {
+    int L = 0;
+    std::vector<int> in, out;
+    std::vector<uint8_t> relu;
+    int max_batch = 0, max_rows = 0;  // max_rows = max_batch rounded up to 64
+    int prec = CODAE_PREC_F32;
+    std::vector<int64_t> w_off, b_off;
+    int64_t n_param = 0, bias_begin = 0;
+    int maxw = 0;
+    std::vector<int64_t> act_off;  // byte offsets of act[0..L-1] and y (index L) inside bufs->acts
+    int64_t act_bytes = 0, dact_one = 0, slab_bytes = 0;
+    std::vector<int> split_k;
+    int esize() const { return prec == CODAE_PREC_BF16 ? 2 : 4; }
+    int rows_for(int B) const { return prec == CODAE_PREC_BF16 ? (int)round_up(B, 64) : B; }
+};
+
+namespace {
+
+int choose_split_k(int N, int K, int rows) {
+    const char* env = getenv("CODAE_WGRAD_SPLITK");
+    const int kt = rows / 64;
+    int s;
+    if (env && atoi(env) > 0) {
+        s = atoi(env);
+    } else {
+        const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+        s = (512 + tiles / 2) / tiles;   // aim at ~2 workgroups per CU
+        if (s > 8) s = 8;
+    }
+    if (s > kt) s = kt;
+    if (s < 1) s = 1;
+    return s;
+}
+
+inline void* act_ptr(const codae_engine* e, const codae_buffers* b, int l) {
+    return reinterpret_cast<char*>(b->acts) + e->act_off[l];
+}
+inline void* dact_ptr(const codae_engine* e, const codae_buffers* b, int l) {
+    return reinterpret_cast<char*>(b->dacts) + (int64_t)(l & 1) * e->dact_one;
+}
+
+int check_common(codae_handle h, const codae_buffers* b, int B) {
+    CODAE_REQUIRE(h != nullptr && b != nullptr, "null handle or buffers");
+    CODAE_REQUIRE(B > 0 && B <= h->max_batch, "batch %d outside (0, %d]", B, h->max_batch);
+    CODAE_REQUIRE(b->params && b->acts, "params/acts buffer missing");
+    CODAE_REQUIRE(h->prec != CODAE_PREC_BF16 || b->shadow_w, "bf16 mode needs shadow_w");
+    return CODAE_OK;
+}
+
+// y = act(x W^T + b) for layer l
+int run_linear(const codae_engine* e, const codae_buffers* b, int l, const void* x, void* y, bool y_f32, int rows,
+               hipStream_t s) {
+    const int N = e->out[l], K = e->in[l];
+    if (e->prec == CODAE_PREC_BF16) {
+        GemmBf16 g{};
+        g.A = reinterpret_cast<const bf16_t*>(x); g.lda = K; g.a_mode = OP_KC;
+        g.B = reinterpret_cast<const bf16_t*>(b->shadow_w) + e->w_off[l]; g.ldb = K; g.b_mode = OP_KC;
+        g.C = y; g.ldc = N; g.c_f32 = y_f32 ? 1 : 0;
+        g.M = rows; g.N = N; g.K = K;
+        g.bias = b->params + e->b_off[l]; g.relu = e->relu[l];
+        g.split_k = 1;
+        return gemm_bf16(g, s);
+    }
+    GemmF32 g{};
+    g.A = reinterpret_cast<const float*>(x); g.a_rs = K; g.a_ks = 1;
+    g.B = b->params + e->w_off[l]; g.b_rs = K; g.b_ks = 1;
+    g.C = reinterpret_cast<float*>(y); g.ldc = N;
+    g.M = rows; g.N = N; g.K = K;
+    g.bias = b->params + e->b_off[l]; g.relu = e->relu[l];
+    return gemm_f32(g, s);
+}
+
+// dW_l = dA_l^T act[l]
+int run_wgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, hipStream_t s) {
+    const int N = e->out[l], K = e->in[l];
+    float* dW = b->grads + e->w_off[l];
+    if (e->prec == CODAE_PREC_BF16) {
+        const int S = e->split_k[l] <= rows / 64 ? e->split_k[l] : rows / 64;
+        GemmBf16 g{};
+        g.A = reinterpret_cast<const bf16_t*>(dact_ptr(e, b, l)); g.lda = N; g.a_mode = OP_KS;
+        g.B = reinterpret_cast<const bf16_t*>(act_ptr(e, b, l)); g.ldb = K; g.b_mode = OP_KS;
+        g.M = N; g.N = K; g.K = rows;
+        g.ldc = K; g.c_f32 = 1; g.split_k = S;
+        if (S > 1) {
+            CODAE_REQUIRE(b->slabs != nullptr, "bf16 wgrad needs the slab workspace");
+            g.C = b->slabs;
+            int rc = gemm_bf16(g, s);
+            if (rc) return rc;
+            return launch_reduce_slabs(reinterpret_cast<const float*>(b->slabs), S, (int64_t)N * K, dW, (int64_t)N * K, s);
+        }
+        g.C = dW;
+        return gemm_bf16(g, s);
+    }
+    GemmF32 g{};
+    g.A = reinterpret_cast<const float*>(dact_ptr(e, b, l)); g.a_rs = 1; g.a_ks = N;
+    g.B = reinterpret_cast<const float*>(act_ptr(e, b, l)); g.b_rs = 1; g.b_ks = K;
+    g.C = dW; g.ldc = K;
+    g.M = N; g.N = K; g.K = rows;
+    return gemm_f32(g, s);
+}
+
+// dA_{l-1} = (dA_l W_l) * [act[l] > 0]  (+ column sums -> db_{l-1});  l == 0 with dx: plain dX in fp32
+int run_dgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, float* dx_f32, hipStream_t s) {
+    const int N = e->out[l], K = e->in[l];
+    const bool to_dx = (dx_f32 != nullptr);
+    if (e->prec == CODAE_PREC_BF16) {
+        GemmBf16 g{};
+        g.A = reinterpret_cast<const bf16_t*>(dact_ptr(e, b, l)); g.lda = N; g.a_mode = OP_KC;
+        g.B = reinterpret_cast<const bf16_t*>(b->shadow_w) + e->w_off[l]; g.ldb = K; g.b_mode = OP_KS;
+        g.M = rows; g.N = K; g.K = N;
+        g.ldc = K; g.split_k = 1;
+        if (to_dx) {
+            g.C = dx_f32; g.c_f32 = 1;
+        } else {
+            g.C = dact_ptr(e, b, l - 1); g.c_f32 = 0;
+            if (e->relu[l - 1]) { g.relu_src = reinterpret_cast<const bf16_t*>(act_ptr(e, b, l)); g.ld_relu = K; }
+            g.colsum = b->grads + e->b_off[l - 1];
+        }
+        return gemm_bf16(g, s);
+    }
+    GemmF32 g{};
+    g.A = reinterpret_cast<const float*>(dact_ptr(e, b, l)); g.a_rs = N; g.a_ks = 1;
+    g.B = b->params + e->w_off[l]; g.b_rs = 1; g.b_ks = K;
+    g.M = rows; g.N = K; g.K = N;
+    g.ldc = K;
+    if (to_dx) {
+        g.C = dx_f32;
+    } else {
+        g.C = reinterpret_cast<float*>(dact_ptr(e, b, l - 1));
+        if (e->relu[l - 1]) { g.relu_src = reinterpret_cast<const float*>(act_ptr(e, b, l)); g.ld_relu = K; }
+        g.colsum = b->grads + e->b_off[l - 1];
+    }
+    return gemm_f32(g, s);
+}
+
+int zero_bias_grads(const codae_engine* e, const codae_buffers* b, hipStream_t s) {
+    CODAE_HIP_CHECK(hipMemsetAsync(b->grads + e->bias_begin, 0, (e->n_param - e->bias_begin) * sizeof(float), s));
+    return CODAE_OK;
+}
+
+// rows [B, rows) of a [rows][width] working-precision matrix -> 0 (bf16 mode pads the batch to 64)
+int zero_pad_rows(const codae_engine* e, void* base, int B, int rows, int width, hipStream_t s) {
+    if (rows > B) {
+        char* p = reinterpret_cast<char*>(base) + (int64_t)B * width * e->esize();
+        CODAE_HIP_CHECK(hipMemsetAsync(p, 0, (int64_t)(rows - B) * width * e->esize(), s));
+    }
+    return CODAE_OK;
+}
+
+// Backward over layers hi-1 ... lo.  Step path (dx == nullptr, step_mode): the chain continues
+// below `lo` in a later call, so the dgrad of every layer > 0 runs.  Drop-in sub-chain: the dgrad
+// of layer `lo` runs only when the caller wants dx, and then lands unmasked in fp32.
+int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi, float* dx, bool step_mode,
+                   hipStream_t s) {
+    const int rows = h->rows_for(B);
+    for (int l = hi - 1; l >= lo; --l) {
+        int rc = run_wgrad(h, b, l, rows, s);
+        if (rc) return rc;
+        if (step_mode ? (l > 0) : (l > lo)) {
+            rc = run_dgrad(h, b, l, rows, nullptr, s);
+        } else if (!step_mode && dx != nullptr) {
+            rc = run_dgrad(h, b, l, B, dx, s);
+        }
+        if (rc) return rc;
+    }
+    return CODAE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* codae_last_error(void) { return g_err; }
+int codae_abi_version(void) { return CODAE_ABI_VERSION; }
+
+int codae_create(const codae_spec* spec, codae_handle* out) {
+    CODAE_REQUIRE(spec && out, "codae_create: null argument");
+    CODAE_REQUIRE(spec->n_layers > 0 && spec->n_layers <= 64, "codae_create: n_layers %d", spec->n_layers);
+    CODAE_REQUIRE(spec->max_batch > 0, "codae_create: max_batch %d", spec->max_batch);
+    CODAE_REQUIRE(spec->precision == CODAE_PREC_F32 || spec->precision == CODAE_PREC_BF16, "codae_create: precision");
+    for (int l = 0; l < spec->n_layers; ++l) {
+        CODAE_REQUIRE(spec->in_features[l] > 0 && spec->out_features[l] > 0, "codae_create: layer %d has an empty side", l);
+        CODAE_REQUIRE(l == 0 || spec->in_features[l] == spec->out_features[l - 1],
+                      "codae_create: layer %d input %d != previous output %d", l, spec->in_features[l], spec->out_features[l - 1]);
+        if (spec->precision == CODAE_PREC_BF16) {
+            // every width is both a GEMM k extent (whole 64-deep tiles) and an n extent
+            if (spec->in_features[l] % 64 != 0 || spec->out_features[l] % 64 != 0) {
+                set_error("codae_create: bf16 mode needs every layer width to be a multiple of 64 (layer %d is %d -> %d); use CODAE_PREC_F32",
+                          l, spec->in_features[l], spec->out_features[l]);
+                return CODAE_E_UNSUPPORTED;
+            }
+        }
+    }
+    codae_engine* e = new codae_engine();
+    e->L = spec->n_layers;
+    e->prec = spec->precision;
+    e->max_batch = spec->max_batch;
+    e->max_rows = (int)round_up(spec->max_batch, 64);
+    int64_t off = 0;
+    for (int l = 0; l < e->L; ++l) {
+        e->in.push_back(spec->in_features[l]);
+        e->out.push_back(spec->out_features[l]);
+        e->relu.push_back(spec->relu[l] ? 1 : 0);
+        e->w_off.push_back(off);
+        off += round_up((int64_t)e->in[l] * e->out[l], 64);
+        if (e->in[l] > e->maxw) e->maxw = e->in[l];
+        if (e->out[l] > e->maxw) e->maxw = e->out[l];
+    }
+    e->bias_begin = off;
+    for (int l = 0; l < e->L; ++l) {
+        e->b_off.push_back(off);
+        off += round_up(e->out[l], 64);
+    }
+    e->n_param = off;
+    int64_t a = 0;
+    for (int l = 0; l < e->L; ++l) {
+        e->act_off.push_back(a);
+        a += round_up((int64_t)e->max_rows * e->in[l] * e->esize(), 256);
+    }
+    e->act_off.push_back(a);  // y, always fp32
+    a += round_up((int64_t)e->max_rows * e->out[e->L - 1] * 4, 256);
+    e->act_bytes = a;
+    e->dact_one = round_up((int64_t)e->max_rows * e->maxw * e->esize(), 256);
+    e->slab_bytes = 0;
+    for (int l = 0; l < e->L; ++l) {
+        int s = 1;
+        if (e->prec == CODAE_PREC_BF16) s = choose_split_k(e->out[l], e->in[l], e->max_rows);
+        e->split_k.push_back(s);
+        if (s > 1) {
+            const int64_t bytes = (int64_t)s * e->in[l] * e->out[l] * 4;
+            if (bytes > e->slab_bytes) e->slab_bytes = bytes;
+        }
+    }
+    *out = e;
+    return CODAE_OK;
+}
+
+int codae_destroy(codae_handle h) {
+    delete h;
+    return CODAE_OK;
+}
+
+int codae_get_sizes(codae_handle h, codae_sizes* out) {
+    CODAE_REQUIRE(h && out, "codae_get_sizes: null argument");
+    out->n_param = h->n_param;
+    out->n_weight = h->prec == CODAE_PREC_BF16 ? h->n_param : 0;
+    out->act_bytes = h->act_bytes;
+    out->dact_bytes = 2 * h->dact_one;
+    out->slab_bytes = h->slab_bytes;
+    out->n_scalars = CODAE_S_COUNT;
+    return CODAE_OK;
+}
+
+int codae_param_offsets(codae_handle h, int32_t layer, int64_t* w_off, int64_t* b_off, int64_t* shadow_off) {
+    CODAE_REQUIRE(h && layer >= 0 && layer < h->L, "codae_param_offsets: layer %d", layer);
+    if (w_off) *w_off = h->w_off[layer];
+    if (b_off) *b_off = h->b_off[layer];
+    if (shadow_off) *shadow_off = h->w_off[layer];
+    return CODAE_OK;
+}
+
+int codae_sync_shadows(codae_handle h, const codae_buffers* b, void* stream) {
+    CODAE_REQUIRE(h && b && b->params, "codae_sync_shadows: null argument");
+    if (h->prec != CODAE_PREC_BF16) return CODAE_OK;
+    CODAE_REQUIRE(b->shadow_w, "codae_sync_shadows: shadow_w missing");
+    return launch_cast_bf16(b->params, reinterpret_cast<bf16_t*>(b->shadow_w), h->n_param, (hipStream_t)stream);
+}
+
+int codae_forward(codae_handle h, const codae_buffers* b, const float* x, float* y, int32_t B, int32_t layer_lo,
+                  int32_t layer_hi, int32_t save_for_backward, void* stream) {
+    int rc = check_common(h, b, B);
+    if (rc) return rc;
+    CODAE_REQUIRE(x && y, "codae_forward: null x or y");
+    CODAE_REQUIRE(layer_lo >= 0 && layer_lo < layer_hi && layer_hi <= h->L, "codae_forward: layer range [%d, %d)", layer_lo, layer_hi);
+    (void)save_for_backward;  // activations always live in the workspace; a later forward overwrites them
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = h->rows_for(B);
+    // ingest x into act[layer_lo] in working precision (no gather, no mask)
+    codae_batch in{};
+    in.data = x; in.B = B; in.io = h->in[layer_lo];
+    rc = launch_gather_corrupt(&in, act_ptr(h, b, layer_lo), h->prec == CODAE_PREC_BF16, s);
+    if (rc) return rc;
+    rc = zero_pad_rows(h, act_ptr(h, b, layer_lo), B, rows, h->in[layer_lo], s);
+    if (rc) return rc;
+    for (int l = layer_lo; l < layer_hi; ++l) {
+        const bool last = (l == layer_hi - 1);
+        if (last) {
+            // the chain's result goes straight to the caller's fp32 tensor (B rows only)
+            rc = run_linear(h, b, l, act_ptr(h, b, l), y, true, B, s);
+        } else {
+            rc = run_linear(h, b, l, act_ptr(h, b, l), act_ptr(h, b, l + 1), false, rows, s);
+        }
+        if (rc) return rc;
+    }
+    return CODAE_OK;
+}
+
+int codae_backward(codae_handle h, const codae_buffers* b, const float* dy, float* dx, int32_t B, int32_t layer_lo,
+                   int32_t layer_hi, void* stream) {
+    int rc = check_common(h, b, B);
+    if (rc) return rc;
+    CODAE_REQUIRE(dy && b->grads && b->dacts, "codae_backward: null dy / grads / dacts");
+    CODAE_REQUIRE(layer_lo >= 0 && layer_lo < layer_hi && layer_hi <= h->L, "codae_backward: layer range [%d, %d)", layer_lo, layer_hi);
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = h->rows_for(B);
+    const int top = layer_hi - 1;
+    // bias gradients are accumulated with atomics by the producers of dA_l: clear this range
+    for (int l = layer_lo; l < layer_hi; ++l)
+        CODAE_HIP_CHECK(hipMemsetAsync(b->grads + h->b_off[l], 0, (size_t)round_up(h->out[l], 64) * sizeof(float), s));
+    // dA_top = dy in working precision; db_top = column sums of dy
+    codae_batch in{};
+    in.data = dy; in.B = B; in.io = h->out[top];
+    rc = launch_gather_corrupt(&in, dact_ptr(h, b, top), h->prec == CODAE_PREC_BF16, s);
+    if (rc) return rc;
+    rc = zero_pad_rows(h, dact_ptr(h, b, top), B, rows, h->out[top], s);
+    if (rc) return rc;
+    rc = launch_colsum_f32(dy, B, h->out[top], b->grads + h->b_off[top], s);
+    if (rc) return rc;
+    return backward_range(h, b, B, layer_lo, layer_hi, dx, false, s);
+}
+
+int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_batch* batch, const codae_hyper* hyper,
+                            float* out_y, void* stream) {
+    CODAE_REQUIRE(batch != nullptr, "codae_step_forward_loss: null batch");
+    int rc = check_common(h, b, batch->B);
+    if (rc) return rc;
+    CODAE_REQUIRE(batch->io == h->in[0] && batch->io == h->out[h->L - 1], "batch.io %d does not match the model (%d -> %d)",
+                  batch->io, h->in[0], h->out[h->L - 1]);
+    CODAE_REQUIRE(b->grads && b->dacts && b->scalars, "codae_step_forward_loss: grads / dacts / scalars missing");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = batch->B, L = h->L;
+    const int rows = h->rows_for(B);
+    const bool bf = h->prec == CODAE_PREC_BF16;
+    rc = launch_gather_corrupt(batch, act_ptr(h, b, 0), bf, s);
+    if (rc) return rc;
+    rc = zero_pad_rows(h, act_ptr(h, b, 0), B, rows, h->in[0], s);
+    if (rc) return rc;
+    float* y = out_y ? out_y : reinterpret_cast<float*>(act_ptr(h, b, L));
+    for (int l = 0; l < L; ++l) {
+        const bool last = (l == L - 1);
+        rc = last ? run_linear(h, b, l, act_ptr(h, b, l), y, true, B, s)
+                  : run_linear(h, b, l, act_ptr(h, b, l), act_ptr(h, b, l + 1), false, rows, s);
+        if (rc) return rc;
+    }
+    if (hyper != nullptr) {
+        rc = zero_bias_grads(h, b, s);
+        if (rc) return rc;
+        const double n_glob = (double)(hyper->loss_scale_rows > 0.f ? hyper->loss_scale_rows : (float)B) * batch->io;
+        rc = zero_pad_rows(h, dact_ptr(h, b, L - 1), B, rows, batch->io, s);
+        if (rc) return rc;
+        rc = launch_mse_loss(batch, y, dact_ptr(h, b, L - 1), bf, (float)(1.0 / n_glob), b->grads + h->b_off[L - 1],
+                             b->scalars, 1, s);
+        if (rc) return rc;
+        return launch_finish_loss(b->scalars, 1.0 / ((double)B * batch->io), s);
+    }
+    rc = launch_mse_loss(batch, y, nullptr, 0, 0.f, nullptr, b->scalars, 0, s);
+    if (rc) return rc;
+    return launch_finish_loss(b->scalars, 1.0 / ((double)B * batch->io), s);
+}
+
+int codae_eval_step(codae_handle h, const codae_buffers* b, const codae_batch* batch, float* out_y, void* stream) {
+    return codae_step_forward_loss(h, b, batch, nullptr, out_y, stream);
+}
+
+int codae_step_backward(codae_handle h, const codae_buffers* b, int32_t B, int32_t layer_lo, int32_t layer_hi, void* stream) {
+    int rc = check_common(h, b, B);
+    if (rc) return rc;
+    CODAE_REQUIRE(b->grads && b->dacts, "codae_step_backward: grads / dacts missing");
+    CODAE_REQUIRE(layer_lo >= 0 && layer_lo < layer_hi && layer_hi <= h->L, "codae_step_backward: layer range [%d, %d)", layer_lo, layer_hi);
+    return backward_range(h, b, B, layer_lo, layer_hi, nullptr, true, (hipStream_t)stream);
+}
+
+int codae_step_update(codae_handle h, const codae_buffers* b, const codae_hyper* hyper, void* stream) {
+    CODAE_REQUIRE(h && b && hyper, "codae_step_update: null argument");
+    CODAE_REQUIRE(b->params && b->grads && b->adam_m && b->adam_v && b->scalars, "codae_step_update: buffer missing");
+    hipStream_t s = (hipStream_t)stream;
+    if (hyper->max_grad_norm > 0.f) {
+        CODAE_HIP_CHECK(hipMemsetAsync(b->scalars + CODAE_S_GRAD_SQ, 0, sizeof(double), s));
+        int rc = launch_sumsq(b->grads, h->n_param, b->scalars + CODAE_S_GRAD_SQ, s);
+        if (rc) return rc;
+    }
+    bf16_t* shadow = h->prec == CODAE_PREC_BF16 ? reinterpret_cast<bf16_t*>(b->shadow_w) : nullptr;
+    CODAE_REQUIRE(h->prec != CODAE_PREC_BF16 || shadow, "codae_step_update: shadow_w missing");
+    return launch_clip_adam(b->params, b->grads, b->adam_m, b->adam_v, h->n_param, hyper, b->scalars + CODAE_S_GRAD_SQ,
+                            shadow, nullptr, s);
+}
+
+int codae_train_step(codae_handle h, const codae_buffers* b, const codae_batch* batch, const codae_hyper* hyper, void* stream) {
+    CODAE_REQUIRE(hyper != nullptr, "codae_train_step: null hyper");
+    int rc = codae_step_forward_loss(h, b, batch, hyper, nullptr, stream);
+    if (rc) return rc;
+    rc = codae_step_backward(h, b, batch->B, 0, h->L, stream);
+    if (rc) return rc;
+    return codae_step_update(h, b, hyper, stream);
+}
+
+// ---- stand-alone ops --------------------------------------------------------------------
+
+int codae_corrupt(const float* x, const float* mask, float* out, int64_t n, void* stream) {
+    return launch_corrupt(x, mask, out, n, (hipStream_t)stream);
+}
+
+int codae_expand_masks(const int32_t* mask_id, const uint8_t* mask_table, const int32_t* k_of_mask, int32_t B, int32_t io,
+                       int32_t k_max, float* masks_out, float* fmask_out, void* stream) {
+    return launch_expand_masks(mask_id, mask_table, k_of_mask, B, io, k_max, masks_out, fmask_out, (hipStream_t)stream);
+}
+
+int codae_mse_loss_fwd_bwd(const float* x, const float* y, const float* fmask, float* dy, int64_t n, float inv_n,
+                           double* scalars, void* stream) {
+    int rc = launch_mse_dense(x, y, fmask, dy, n, inv_n, scalars, (hipStream_t)stream);
+    if (rc) return rc;
+    return launch_finish_loss(scalars, 1.0 / (double)n, (hipStream_t)stream);
+}
+
+int codae_clip_adam(float* params, float* grads, float* adam_m, float* adam_v, int64_t n, const codae_hyper* hyper,
+                    double* scalars, void* stream) {
+    CODAE_REQUIRE(hyper && scalars, "codae_clip_adam: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (hyper->max_grad_norm > 0.f) {
+        CODAE_HIP_CHECK(hipMemsetAsync(scalars + CODAE_S_GRAD_SQ, 0, sizeof(double), s));
+        int rc = launch_sumsq(grads, n, scalars + CODAE_S_GRAD_SQ, s);
+        if (rc) return rc;
+    }
+    return launch_clip_adam(params, grads, adam_m, adam_v, n, hyper, scalars + CODAE_S_GRAD_SQ, nullptr, nullptr, s);
+}
+
+// ---- GEMM primitives ------------------------------------------------------------------------
+
+int codae_linear_f32(const float* x, const float* W, const float* bias, float* y, int32_t M, int32_t N, int32_t K,
+                     int32_t relu, void* stream) {
+    CODAE_REQUIRE(x && W && y, "codae_linear_f32: null operand");
+    GemmF32 g{};
+    g.A = x; g.a_rs = K; g.a_ks = 1;
+    g.B = W; g.b_rs = K; g.b_ks = 1;
+    g.C = y; g.ldc = N; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.relu = relu;
+    return gemm_f32(g, (hipStream_t)stream);
+}
+
+int codae_dgrad_f32(const float* dy, const float* W, const float* relu_src, float* dx, int32_t M, int32_t N, int32_t K,
+                    void* stream) {
+    CODAE_REQUIRE(dy && W && dx, "codae_dgrad_f32: null operand");
+    GemmF32 g{};
+    g.A = dy; g.a_rs = N; g.a_ks = 1;
+    g.B = W; g.b_rs = 1; g.b_ks = K;
+    g.C = dx; g.ldc = K; g.M = M; g.N = K; g.K = N;
+    g.relu_src = relu_src; g.ld_relu = K;
+    return gemm_f32(g, (hipStream_t)stream);
+}
+
+int codae_wgrad_f32(const float* dy, const float* x, float* dW, float* db, int32_t M, int32_t N, int32_t K, void* stream) {
+    CODAE_REQUIRE(dy && x && dW, "codae_wgrad_f32: null operand");
+    GemmF32 g{};
+    g.A = dy; g.a_rs = 1; g.a_ks = N;
+    g.B = x; g.b_rs = 1; g.b_ks = K;
+    g.C = dW; g.ldc = K; g.M = N; g.N = K; g.K = M;
+    int rc = gemm_f32(g, (hipStream_t)stream);
+    if (rc) return rc;
+    if (db) {
+        CODAE_HIP_CHECK(hipMemsetAsync(db, 0, (size_t)N * sizeof(float), (hipStream_t)stream));
+        return launch_colsum_f32(dy, M, N, db, (hipStream_t)stream);
+    }
+    return CODAE_OK;
+}
+
+int codae_linear_bf16(const void* x, const void* W, const float* bias, void* y, int32_t y_f32, int32_t M, int32_t N,
+                      int32_t K, int32_t relu, void* stream) {
+    CODAE_REQUIRE(x && W && y, "codae_linear_bf16: null operand");
+    GemmBf16 g{};
+    g.A = reinterpret_cast<const bf16_t*>(x); g.lda = K; g.a_mode = OP_KC;
+    g.B = reinterpret_cast<const bf16_t*>(W); g.ldb = K; g.b_mode = OP_KC;
+    g.C = y; g.ldc = N; g.c_f32 = y_f32; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.relu = relu; g.split_k = 1;
+    return gemm_bf16(g, (hipStream_t)stream);
+}
+
+int codae_dgrad_bf16(const void* dy, const void* W, const void* relu_src, void* dx, float* db_prev, int32_t M, int32_t N,
+                     int32_t K, void* stream) {
+    CODAE_REQUIRE(dy && W && dx, "codae_dgrad_bf16: null operand");
+    GemmBf16 g{};
+    g.A = reinterpret_cast<const bf16_t*>(dy); g.lda = N; g.a_mode = OP_KC;
+    g.B = reinterpret_cast<const bf16_t*>(W); g.ldb = K; g.b_mode = OP_KS;
+    g.C = dx; g.ldc = K; g.c_f32 = 0; g.M = M; g.N = K; g.K = N;
+    g.relu_src = reinterpret_cast<const bf16_t*>(relu_src); g.ld_relu = K;
+    g.colsum = db_prev; g.split_k = 1;
+    return gemm_bf16(g, (hipStream_t)stream);
+}
+
+int codae_wgrad_bf16(const void* dy, const void* x, float* dW, void* slabs, int64_t slab_bytes, int32_t M, int32_t N,
+                     int32_t K, void* stream) {
+    CODAE_REQUIRE(dy && x && dW, "codae_wgrad_bf16: null operand");
+    CODAE_REQUIRE(M % 64 == 0, "codae_wgrad_bf16: batch rows %d must be a multiple of 64 (pad with zero rows)", M);
+    int S = choose_split_k(N, K, M);
+    while (S > 1 && (slabs == nullptr || (int64_t)S * N * K * 4 > slab_bytes)) --S;
+    GemmBf16 g{};
+    g.A = reinterpret_cast<const bf16_t*>(dy); g.lda = N; g.a_mode = OP_KS;
+    g.B = reinterpret_cast<const bf16_t*>(x); g.ldb = K; g.b_mode = OP_KS;
+    g.ldc = K; g.c_f32 = 1; g.M = N; g.N = K; g.K = M; g.split_k = S;
+    g.C = S > 1 ? slabs : (void*)dW;
+    int rc = gemm_bf16(g, (hipStream_t)stream);
+    if (rc) return rc;
+    if (S > 1) return launch_reduce_slabs(reinterpret_cast<const float*>(slabs), S, (int64_t)N * K, dW, (int64_t)N * K, (hipStream_t)stream);
+    return CODAE_OK;
+}
+
+int codae_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    return launch_cast_bf16(src, reinterpret_cast<bf16_t*>(dst), n, (hipStream_t)stream);
+}
+
+}  // extern "C"

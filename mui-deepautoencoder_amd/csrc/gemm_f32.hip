@@ -1,0 +1,175 @@
+// Exact-fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32): the parity-mode
+// engine of the Linear chain, and the path for shapes the bf16 kernels cannot take
+// (abalone: 11-wide layers).  The MFMA result is bit-for-bit a k-ordered fp32 fma chain,
+// so this is the arithmetic of torch.nn.Linear's fp32 sgemm up to summation order.
+//
+//   C[i][j] = epi( sum_k A(i,k) * B(j,k) )
+//     forward  (embedding_denoising_autoencoder.py:166,183): A = x [M][K], B = W [N][K]
+//     dgrad    (autograd of the above):                      A = dy [M][N], B(j=k', kk=n) = W[n][k']
+//     wgrad    :                                             A(i=n, kk=m) = dy[m][n], B(j=k', kk=m) = x[m][k']
+//
+// Tile: 128 x 128 x 16 per 256-thread workgroup; each of the 4 waves owns a 64 x 64
+// sub-tile (2 x 2 MFMA 32x32 accumulators).  Operands go through LDS in a k-major image
+// S[k][row] (row stride 132 floats) so that both MFMA operand reads are conflict-free
+// ds_read_b32 across 32 consecutive banks; global loads follow whichever index is
+// contiguous in memory and are prefetched into registers one tile ahead.
+#include "codae_common.h"
+
+namespace codae {
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, LD = 132, NT = 256;
+
+// Load a 128(rows) x 16(k) tile into 8 registers per thread.
+//   KC : element(r,k) = P[r*rs + k]      thread -> row (t>>2)+64p, k 4*(t&3)..+3
+//   !KC: element(r,k) = P[k*ks + r]      thread -> k (t>>5)+8p,  rows 4*(t&31)..+3
+template <bool KC>
+__device__ __forceinline__ void load_tile(float (&reg)[8], const float* __restrict__ P, int64_t rs, int64_t ks,
+                                          int r0, int k0, int R, int K, bool vec_ok, int t) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if constexpr (KC) {
+            const int r = r0 + (t >> 2) + 64 * p;
+            const int k = k0 + 4 * (t & 3);
+            const float* src = P + (int64_t)r * rs + k;
+            if (r < R && vec_ok && k + 3 < K) {
+                const float4 v = *reinterpret_cast<const float4*>(src);
+                reg[4 * p + 0] = v.x; reg[4 * p + 1] = v.y; reg[4 * p + 2] = v.z; reg[4 * p + 3] = v.w;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) reg[4 * p + c] = (r < R && k + c < K) ? src[c] : 0.f;
+            }
+        } else {
+            const int k = k0 + (t >> 5) + 8 * p;
+            const int r = r0 + 4 * (t & 31);
+            const float* src = P + (int64_t)k * ks + r;
+            if (k < K && vec_ok && r + 3 < R) {
+                const float4 v = *reinterpret_cast<const float4*>(src);
+                reg[4 * p + 0] = v.x; reg[4 * p + 1] = v.y; reg[4 * p + 2] = v.z; reg[4 * p + 3] = v.w;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) reg[4 * p + c] = (k < K && r + c < R) ? src[c] : 0.f;
+            }
+        }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile(float* S, const float (&reg)[8], int t) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if constexpr (KC) {
+            const int r = (t >> 2) + 64 * p;
+            const int k = 4 * (t & 3);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) S[(k + c) * LD + r] = reg[4 * p + c];
+        } else {
+            const int k = (t >> 5) + 8 * p;
+            const int r = 4 * (t & 31);
+            *reinterpret_cast<float4*>(&S[k * LD + r]) =
+                make_float4(reg[4 * p + 0], reg[4 * p + 1], reg[4 * p + 2], reg[4 * p + 3]);
+        }
+    }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmF32 g, bool a_vec, bool b_vec) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * LD];
+    float* As = smem;
+    float* Bs = smem + BK * LD;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, w = t >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int li = lane & 31, kh = lane >> 5;
+    const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    float ra[8], rb[8];
+    load_tile<A_KC>(ra, g.A, g.a_rs, g.a_ks, i0, 0, g.M, g.K, a_vec, t);
+    load_tile<B_KC>(rb, g.B, g.b_rs, g.b_ks, j0, 0, g.N, g.K, b_vec, t);
+
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+        __syncthreads();
+        store_tile<A_KC>(As, ra, t);
+        store_tile<B_KC>(Bs, rb, t);
+        __syncthreads();
+        if (k0 + BK < g.K) {
+            load_tile<A_KC>(ra, g.A, g.a_rs, g.a_ks, i0, k0 + BK, g.M, g.K, a_vec, t);
+            load_tile<B_KC>(rb, g.B, g.b_rs, g.b_ks, j0, k0 + BK, g.N, g.K, b_vec, t);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            const int kr = 2 * kk + kh;
+            const float a0 = As[kr * LD + 64 * wr + li];
+            const float a1 = As[kr * LD + 64 * wr + 32 + li];
+            const float b0 = Bs[kr * LD + 64 * wc + li];
+            const float b1 = Bs[kr * LD + 64 * wc + 32 + li];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+
+    // epilogue: D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int j = j0 + 64 * wc + 32 * ni + li;
+        const float bj = (g.bias != nullptr && j < g.N) ? g.bias[j] : 0.f;
+        float csum = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + 64 * wr + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (i < g.M && j < g.N) {
+                    float v = acc[mi][ni][r] + bj;
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    if (g.relu_src != nullptr) v = (g.relu_src[(int64_t)i * g.ld_relu + j] > 0.f) ? v : 0.f;
+                    g.C[(int64_t)i * g.ldc + j] = v;
+                    csum += v;
+                }
+            }
+        }
+        if (g.colsum != nullptr) {
+            csum += __shfl_xor(csum, 32);
+            if (kh == 0 && j < g.N) atomicAdd(&g.colsum[j], csum);
+        }
+    }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+int gemm_f32(const GemmF32& g, hipStream_t s) {
+    CODAE_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm_f32: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);
+    CODAE_REQUIRE(g.a_ks == 1 || g.a_rs == 1, "gemm_f32: operand A needs a unit stride");
+    CODAE_REQUIRE(g.b_ks == 1 || g.b_rs == 1, "gemm_f32: operand B needs a unit stride");
+    const bool a_kc = (g.a_ks == 1);
+    const bool b_kc = (g.b_ks == 1);
+    const bool a_vec = aligned16(g.A) && ((a_kc ? g.a_rs : g.a_ks) % 4 == 0);
+    const bool b_vec = aligned16(g.B) && ((b_kc ? g.b_rs : g.b_ks) % 4 == 0);
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM);
+    CODAE_REQUIRE(grid.y <= 65535, "gemm_f32: M=%d too large", g.M);
+    if (a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(NT), 0, s, g, a_vec, b_vec);
+    else if (a_kc && !b_kc)
+        hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(NT), 0, s, g, a_vec, b_vec);
+    else if (!a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(NT), 0, s, g, a_vec, b_vec);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(NT), 0, s, g, a_vec, b_vec);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+}  // namespace codae

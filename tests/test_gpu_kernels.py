@@ -1,0 +1,263 @@
+"""Kernel-level parity on a real MI355X, through the C ABI (ctypes).
+
+fp32 kernels: against float64 references (tolerance rtol 1e-3 / atol 1e-5 of north_star; the
+observed error is ~1e-6).  bf16 kernels: exact equality on small-integer data (every product and
+partial sum is exactly representable, so any wrong lane/fragment mapping shows) plus a tolerance
+check on random data.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from codae import hip as H
+    H.lib()
+    return H
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+def f64(t):
+    return t.detach().double().cpu().numpy()
+
+
+SHAPES_F32 = [(1, 1, 1), (37, 11, 11), (64, 11, 11), (130, 200, 77), (256, 256, 256), (300, 129, 1000), (1024, 384, 384)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES_F32)
+@pytest.mark.parametrize("relu", [0, 1])
+def test_linear_f32(hip, M, N, K, relu):
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
+    x = torch.randn(M, K, generator=g).to(dev())
+    W = torch.randn(N, K, generator=g).to(dev())
+    b = torch.randn(N, generator=g).to(dev())
+    y = torch.full((M, N), float("nan"), device=dev())
+    hip.check(hip.lib().codae_linear_f32(hip.ptr(x), hip.ptr(W), hip.ptr(b), hip.ptr(y), M, N, K, relu, hip.current_stream()))
+    sync()
+    ref = f64(x) @ f64(W).T + f64(b)
+    if relu:
+        ref = np.maximum(ref, 0)
+    assert np.allclose(f64(y), ref, rtol=1e-3, atol=1e-4 * np.sqrt(K))
+    assert np.abs(f64(y) - ref).max() < 2e-5 * K ** 0.5 * 4
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES_F32)
+def test_dgrad_f32(hip, M, N, K):
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    dy = torch.randn(M, N, generator=g).to(dev())
+    W = torch.randn(N, K, generator=g).to(dev())
+    h = torch.randn(M, K, generator=g).to(dev())
+    dx = torch.full((M, K), float("nan"), device=dev())
+    hip.check(hip.lib().codae_dgrad_f32(hip.ptr(dy), hip.ptr(W), hip.ptr(h), hip.ptr(dx), M, N, K, hip.current_stream()))
+    sync()
+    ref = (f64(dy) @ f64(W)) * (f64(h) > 0)
+    assert np.abs(f64(dx) - ref).max() < 1e-4 * N ** 0.5
+    hip.check(hip.lib().codae_dgrad_f32(hip.ptr(dy), hip.ptr(W), None, hip.ptr(dx), M, N, K, hip.current_stream()))
+    sync()
+    assert np.abs(f64(dx) - f64(dy) @ f64(W)).max() < 1e-4 * N ** 0.5
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES_F32)
+def test_wgrad_f32(hip, M, N, K):
+    g = torch.Generator(device="cpu").manual_seed(M * N + K)
+    dy = torch.randn(M, N, generator=g).to(dev())
+    x = torch.randn(M, K, generator=g).to(dev())
+    dW = torch.full((N, K), float("nan"), device=dev())
+    db = torch.full((N,), float("nan"), device=dev())
+    hip.check(hip.lib().codae_wgrad_f32(hip.ptr(dy), hip.ptr(x), hip.ptr(dW), hip.ptr(db), M, N, K, hip.current_stream()))
+    sync()
+    assert np.abs(f64(dW) - f64(dy).T @ f64(x)).max() < 1e-4 * M ** 0.5
+    assert np.abs(f64(db) - f64(dy).sum(0)).max() < 1e-4 * M ** 0.5
+
+
+def test_linear_f32_full_size(hip):
+    """BASELINE config 3x512, batch 8192: one encoder GEMM; checked on a row/column sample in float64
+    and by linearity (f(a x1 + x2) = a f(x1) + f(x2) without bias)."""
+    M, N, K = 8192, 1536, 1536
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.rand(M, K, generator=g).to(dev())
+    W = ((torch.rand(N, K, generator=g) * 2 - 1) * (6 / (N + K)) ** 0.5).to(dev())
+    b = torch.randn(N, generator=g).to(dev())
+    y = torch.empty(M, N, device=dev())
+    L = hip.lib()
+    hip.check(L.codae_linear_f32(hip.ptr(x), hip.ptr(W), hip.ptr(b), hip.ptr(y), M, N, K, 0, hip.current_stream()))
+    sync()
+    rows = [0, 1, 127, 128, 4095, 8191]
+    ref = f64(x[rows]) @ f64(W).T + f64(b)
+    assert np.allclose(f64(y[rows]), ref, rtol=1e-3, atol=1e-5)
+    x2 = torch.rand(M, K, generator=g).to(dev())
+    y2 = torch.empty_like(y); y3 = torch.empty_like(y)
+    hip.check(L.codae_linear_f32(hip.ptr(x2), hip.ptr(W), None, hip.ptr(y2), M, N, K, 0, hip.current_stream()))
+    x3 = (0.5 * x + x2).contiguous()
+    hip.check(L.codae_linear_f32(hip.ptr(x3), hip.ptr(W), None, hip.ptr(y3), M, N, K, 0, hip.current_stream()))
+    sync()
+    assert torch.allclose(y3, 0.5 * (y - b) + y2, rtol=1e-3, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------
+# bf16 MFMA kernels
+# ---------------------------------------------------------------------------------------------
+
+def ints(shape, g, lo=-3, hi=4):
+    return torch.randint(lo, hi, shape, generator=g).float()
+
+
+SHAPES_BF16 = [(128, 128, 64), (64, 64, 64), (200, 192, 128), (256, 384, 384), (1000, 832, 128), (8, 64, 64)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES_BF16)
+@pytest.mark.parametrize("y_f32", [0, 1])
+def test_linear_bf16_exact_integers(hip, M, N, K, y_f32):
+    g = torch.Generator(device="cpu").manual_seed(M + 2 * N + 3 * K)
+    x, W, b = ints((M, K), g), ints((N, K), g), ints((N,), g)
+    xb, Wb = x.to(dev()).bfloat16(), W.to(dev()).bfloat16()
+    bd = b.to(dev())
+    y = torch.full((M, N), float("nan"), device=dev(), dtype=torch.float32 if y_f32 else torch.bfloat16)
+    hip.check(hip.lib().codae_linear_bf16(hip.ptr(xb), hip.ptr(Wb), hip.ptr(bd), hip.ptr(y), y_f32, M, N, K, 1, hip.current_stream()))
+    sync()
+    ref = np.maximum(f64(x) @ f64(W).T + f64(b), 0)
+    if not y_f32:
+        ref = f64(torch.from_numpy(ref).bfloat16())
+    assert np.array_equal(f64(y.float()), ref)
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES_BF16)
+def test_dgrad_bf16_exact_integers(hip, M, N, K):
+    # dx[M][K] = (dy[M][N] . W[N][K]) * [h > 0]; here the reduction dim is N (must be % 64)
+    if N % 64:
+        pytest.skip("reduction dim must be a multiple of 64")
+    g = torch.Generator(device="cpu").manual_seed(11 * M + N + K)
+    dy, W, h = ints((M, N), g, -2, 3), ints((N, K), g, -2, 3), ints((M, K), g, -1, 2)
+    dyb, Wb, hb = dy.to(dev()).bfloat16(), W.to(dev()).bfloat16(), h.to(dev()).bfloat16()
+    dx = torch.full((M, K), float("nan"), device=dev(), dtype=torch.bfloat16)
+    db = torch.zeros(K, device=dev())
+    hip.check(hip.lib().codae_dgrad_bf16(hip.ptr(dyb), hip.ptr(Wb), hip.ptr(hb), hip.ptr(dx), hip.ptr(db), M, N, K, hip.current_stream()))
+    sync()
+    ref = (f64(dy) @ f64(W)) * (f64(h) > 0)
+    refb = f64(torch.from_numpy(ref).bfloat16())
+    assert np.array_equal(f64(dx.float()), refb)
+    # column sums are taken on the fp32 values before rounding to bf16
+    assert np.allclose(f64(db), ref.sum(0), rtol=0, atol=1e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (128, 128, 128), (512, 192, 128), (1024, 384, 384), (8192, 128, 832)])
+def test_wgrad_bf16_exact_integers(hip, M, N, K):
+    g = torch.Generator(device="cpu").manual_seed(M + N * K)
+    dy, x = ints((M, N), g, -2, 3), ints((M, K), g, -2, 3)
+    dyb, xb = dy.to(dev()).bfloat16(), x.to(dev()).bfloat16()
+    dW = torch.full((N, K), float("nan"), device=dev())
+    slabs = torch.empty(8 * N * K, device=dev())
+    hip.check(hip.lib().codae_wgrad_bf16(hip.ptr(dyb), hip.ptr(xb), hip.ptr(dW), hip.ptr(slabs), slabs.numel() * 4, M, N, K, hip.current_stream()))
+    sync()
+    assert np.array_equal(f64(dW), f64(dy).T @ f64(x))
+    # and without the slab workspace (split-K disabled)
+    dW2 = torch.full((N, K), float("nan"), device=dev())
+    hip.check(hip.lib().codae_wgrad_bf16(hip.ptr(dyb), hip.ptr(xb), hip.ptr(dW2), None, 0, M, N, K, hip.current_stream()))
+    sync()
+    assert np.array_equal(f64(dW2), f64(dW))
+
+
+def test_bf16_gemms_full_size_random(hip):
+    """3x512 / batch 8192 shapes on random data; reference = float64 product of the bf16-rounded
+    operands on sampled rows; error bound = fp32 accumulation + one bf16 rounding of the output."""
+    M, N, K = 8192, 1536, 1536
+    L = hip.lib()
+    g = torch.Generator(device="cpu").manual_seed(17)
+    x = torch.rand(M, K, generator=g).to(dev()).bfloat16()
+    W = ((torch.rand(N, K, generator=g) * 2 - 1) * 0.05).to(dev()).bfloat16()
+    b = torch.randn(N, generator=g).to(dev())
+    y = torch.empty(M, N, device=dev(), dtype=torch.bfloat16)
+    hip.check(L.codae_linear_bf16(hip.ptr(x), hip.ptr(W), hip.ptr(b), hip.ptr(y), 0, M, N, K, 0, hip.current_stream()))
+    sync()
+    rows = [0, 63, 64, 4097, 8191]
+    ref = f64(x[rows].float()) @ f64(W.float()).T + f64(b)
+    assert np.allclose(f64(y[rows].float()), ref, rtol=1e-2, atol=1e-2)
+    dy = (torch.randn(M, N, generator=g) * 1e-3).to(dev()).bfloat16()
+    dx = torch.empty(M, K, device=dev(), dtype=torch.bfloat16)
+    hip.check(L.codae_dgrad_bf16(hip.ptr(dy), hip.ptr(W), None, hip.ptr(dx), None, M, N, K, hip.current_stream()))
+    dW = torch.empty(N, K, device=dev())
+    slabs = torch.empty(8 * N * K, device=dev())
+    hip.check(L.codae_wgrad_bf16(hip.ptr(dy), hip.ptr(x), hip.ptr(dW), hip.ptr(slabs), slabs.numel() * 4, M, N, K, hip.current_stream()))
+    sync()
+    ref = f64(dy[rows].float()) @ f64(W.float())
+    assert np.allclose(f64(dx[rows].float()), ref, rtol=1e-2, atol=1e-5)
+    cols = [0, 5, 777, 1535]
+    ref = f64(dy.float())[:, cols].T @ f64(x.float())
+    assert np.allclose(f64(dW[cols]), ref, rtol=1e-3, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+# elementwise kernels vs the oracle
+# ---------------------------------------------------------------------------------------------
+
+def test_corrupt_and_expand_masks(hip):
+    from oracle import dae_oracle as O
+    arch = [{"size": 3, "position": 0}] + [{"size": 1, "position": 3 + i} for i in range(8)]
+    bm, nmr, per_k = O.corrupter_tables(arch, 2)
+    rng = np.random.default_rng(0)
+    N, B = 50, 37
+    mtu = np.stack([rng.permutation(bm.shape[0]) for _ in range(N)])
+    idx = rng.integers(0, N, B)
+    masks, fmask = O.get_masks(bm, nmr, mtu, 2, idx, 3)
+    ids = torch.tensor(mtu[idx, 3], dtype=torch.int32, device=dev())
+    table = torch.tensor(bm, dtype=torch.uint8, device=dev())
+    kof = torch.tensor(nmr, dtype=torch.int32, device=dev())
+    mo = torch.empty(2, B, 11, device=dev()); fo = torch.empty(B, 11, device=dev())
+    hip.check(hip.lib().codae_expand_masks(hip.ptr(ids), hip.ptr(table), hip.ptr(kof), B, 11, 2, hip.ptr(mo), hip.ptr(fo), hip.current_stream()))
+    x = torch.tensor(rng.random((B, 11)), dtype=torch.float32, device=dev())
+    out = torch.empty_like(x)
+    hip.check(hip.lib().codae_corrupt(hip.ptr(x), hip.ptr(fo), hip.ptr(out), x.numel(), hip.current_stream()))
+    sync()
+    assert np.array_equal(mo[0].cpu().numpy(), masks[0]) and np.array_equal(mo[1].cpu().numpy(), masks[1])
+    assert np.array_equal(fo.cpu().numpy(), fmask)
+    assert np.array_equal(out.cpu().numpy(), O.corrupt(x.cpu().numpy(), fmask))
+
+
+@pytest.mark.parametrize("n", [1, 5, 64, 1000, 23608320 // 8])
+def test_clip_adam_matches_torch(hip, n):
+    g = torch.Generator(device="cpu").manual_seed(n)
+    p0 = torch.randn(n, generator=g); g0 = torch.randn(n, generator=g) * 3
+    ref_p = torch.nn.Parameter(p0.clone().double())
+    opt = torch.optim.Adam([ref_p], lr=1e-3, weight_decay=1e-2)
+    p = p0.clone().to(dev()); m = torch.zeros(n, device=dev()); v = torch.zeros(n, device=dev())
+    sc = torch.zeros(8, dtype=torch.float64, device=dev())
+    for step in range(1, 4):
+        grad = g0 * step
+        ref_p.grad = grad.clone().double()
+        total = torch.nn.utils.clip_grad_norm_([ref_p], 1.0)
+        opt.step()
+        gd = grad.clone().to(dev())
+        hp = hip.Hyper(1e-3, 1e-2, 0.9, 0.999, 1e-8, 1.0, step, 0.0)
+        hip.check(hip.lib().codae_clip_adam(hip.ptr(p), hip.ptr(gd), hip.ptr(m), hip.ptr(v), n, C.byref(hp), hip.ptr(sc), hip.current_stream()))
+        sync()
+        assert abs(float(sc[hip.S_GRAD_SQ]) ** 0.5 - float(total)) < 1e-4 * float(total) + 1e-6
+        assert np.allclose(f64(p), f64(ref_p), rtol=1e-3, atol=1e-5)
+
+
+def test_mse_loss_dense(hip):
+    rng = np.random.default_rng(3)
+    B, io = 77, 48
+    x = rng.random((B, io), dtype=np.float32); y = rng.random((B, io), dtype=np.float32)
+    fm = (rng.random((B, io)) > 0.3).astype(np.float32)
+    xd, yd, fd = (torch.tensor(a, device=dev()) for a in (x, y, fm))
+    dy = torch.empty_like(xd); sc = torch.zeros(8, dtype=torch.float64, device=dev())
+    hip.check(hip.lib().codae_mse_loss_fwd_bwd(hip.ptr(xd), hip.ptr(yd), hip.ptr(fd), hip.ptr(dy), B * io, 1.0 / (B * io), hip.ptr(sc), hip.current_stream()))
+    sync()
+    d = x.astype(np.float64) - y
+    assert np.allclose(f64(dy), -2 * d / (B * io), rtol=1e-5, atol=1e-9)
+    assert abs(float(sc[hip.S_SQ_FULL]) - (d ** 2).sum()) < 1e-3
+    assert abs(float(sc[hip.S_SQ_PARTIAL]) - ((1 - fm) * d ** 2).sum()) < 1e-3
+    assert abs(float(sc[hip.S_LAST_LOSS]) - (d ** 2).mean()) < 1e-6

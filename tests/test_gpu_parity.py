@@ -1,0 +1,265 @@
+"""Engine-level parity on a real MI355X: the reference training scripts' runs (golden fixtures
+generated from the reference itself) replayed through the HIP path, in both integration modes:
+
+  fused    : HipEmbeddingTrainer (codae_train_step: gather+corrupt, GEMM chain, loss, clip, Adam)
+  drop-in  : codae.model classes + torch MSELoss / CombinedCriterion / clip_grad_norm_ / Adam,
+             i.e. what the reference scripts execute when they import this package.
+
+Tolerance: rtol 1e-3 / atol 1e-5 (BASELINE.json north_star) in fp32 mode.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from golden_util import Golden, close, max_err
+from replay import replay_abalone, replay_embedding
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+DEV = "cuda:0"
+
+
+class FusedTrainerAdapter:
+    """step/evaluate interface of tests/replay.py on top of HipEmbeddingTrainer."""
+
+    def __init__(self, g, precision):
+        from codae.train import HipEmbeddingTrainer
+        m = g.meta
+        sched = [(w.shape[1], w.shape[0], r) for (w, _), r in zip(g.params("init"), g.relu_flags())]
+        self.t = HipEmbeddingTrainer(sched, torch.tensor(g["data"]), torch.tensor(g["binary_masks"]).to(torch.uint8),
+                                     torch.tensor(g["mask_to_use"]).to(torch.int32), m["lr"], m["weight_decay"],
+                                     clip=1.0, max_batch=m["batch"], precision=precision, device=DEV)
+        self.t.load_params(g.params("init"))
+        self.data = g["data"]
+        self.pending = None
+
+    def _idx(self, x):
+        return self.pending
+
+    def step(self, x, fmask):
+        idx = torch.tensor(self.pending_idx, dtype=torch.int32, device=DEV)
+        self.t.engine.zero_metric_sums()
+        self.t.train_batch(idx, run=self.pending_run)
+        sq, sqp, gsq, loss = self.t.engine.read_scalars()
+        return {"loss": loss, "grad_norm": math.sqrt(gsq), "sq_full": sq, "sq_partial": sqp}
+
+    def evaluate(self, x, fmask):
+        idx = torch.tensor(self.pending_idx, dtype=torch.int32, device=DEV)
+        self.t.engine.zero_metric_sums()
+        y = self.t.eval_batch(idx, run=self.pending_run, want_y=True)
+        sq, sqp, _, _ = self.t.engine.read_scalars()
+        return {"y": y.cpu().numpy(), "sq_full": sq, "sq_partial": sqp}
+
+
+def _replay_fused(g, adapter):
+    """replay_embedding feeds x/fmask; the fused path wants indices: wrap the calls list."""
+    calls = g.calls()
+    it = iter(calls)
+    orig_step, orig_eval = adapter.step, adapter.evaluate
+
+    def step(x, fmask):
+        adapter.pending_idx, adapter.pending_run = next(it)
+        return orig_step(x, fmask)
+
+    def evaluate(x, fmask):
+        adapter.pending_idx, adapter.pending_run = next(it)
+        return orig_eval(x, fmask)
+    adapter.step, adapter.evaluate = step, evaluate
+    return replay_embedding(g, adapter)
+
+
+@pytest.mark.parametrize("name", ["embedding_square", "embedding_taper"])
+def test_fused_step_replays_reference_run_f32(name):
+    g = Golden(name)
+    ad = FusedTrainerAdapter(g, "f32")
+    book, steps, _ = _replay_fused(g, ad)
+    assert close(steps["loss"], g["step_loss"]), max_err(steps["loss"], g["step_loss"])
+    assert close(steps["grad_norm"], g["step_grad_norm"]), max_err(steps["grad_norm"], g["step_grad_norm"])
+    for k in ("ftl", "ptl", "fvl", "pvl", "rl"):
+        assert close(book[k], g["book_" + k]), (k, book[k], g["book_" + k])
+    eng = ad.t.engine
+    for l, (gw, gb) in enumerate(g.params("final")):
+        assert close(eng.weight(l).cpu().numpy(), gw), ("W", l)
+        assert close(eng.bias(l).cpu().numpy(), gb), ("b", l)
+    for l, ((mw, mb), (vw, vb)) in enumerate(zip(g.list("adam_m"), g.list("adam_v"))):
+        assert close(eng._view(eng.adam_m, l, False).cpu().numpy(), mw, atol=1e-7)
+        assert close(eng._view(eng.adam_m, l, True).cpu().numpy(), mb, atol=1e-7)
+        assert close(eng._view(eng.adam_v, l, False).cpu().numpy(), vw, atol=1e-10)
+        assert close(eng._view(eng.adam_v, l, True).cpu().numpy(), vb, atol=1e-10)
+
+
+def test_fused_first_step_grads_f32():
+    g = Golden("embedding_square")
+    ad = FusedTrainerAdapter(g, "f32")
+    idx, run = g.calls()[0]
+    eng = ad.t.engine
+    batch = ad.t._batch(torch.tensor(idx, dtype=torch.int32, device=DEV), run)
+    hyper = eng.hyper(g.meta["lr"], g.meta["weight_decay"], 1.0, global_rows=len(idx))
+    eng.step_forward_loss(batch, hyper)
+    eng.step_backward(len(idx), 0, eng.L)
+    torch.cuda.synchronize()
+    for l, (gw, gb) in enumerate(g.list("grad0")):
+        assert close(eng.weight_grad(l).cpu().numpy(), gw, atol=1e-8), ("dW", l)
+        assert close(eng.bias_grad(l).cpu().numpy(), gb, atol=1e-8), ("db", l)
+
+
+class DropInEmbeddingAdapter:
+    """The reference script's loop body with this package's model + torch loss/optimizer."""
+
+    def __init__(self, g):
+        from codae.model import EmbeddingDenoisingAutoencoder
+        m = g.meta
+        torch.manual_seed(m["seed"])           # same seed as the golden run -> same Xavier draws
+        self.model = EmbeddingDenoisingAutoencoder(m["S"] * m["E"], m["z"], m["E"], m["nb_input_layer"],
+                                                   m["nb_output_layer"], False)
+        self.init_matches = all(np.array_equal(p.detach().numpy(), g["init__" + n.replace(".", "__")])
+                                for n, p in self.model.state_dict().items())
+        self.model.to(DEV)
+        self.opt = torch.optim.Adam(self.model.parameters(), lr=m["lr"], weight_decay=m["weight_decay"])
+        self.crit = torch.nn.MSELoss(reduction="mean")
+
+    def step(self, x, fmask):
+        x = torch.tensor(x, device=DEV); fmask = torch.tensor(fmask, device=DEV)
+        c = self.model.corrupt(input_data=x, mask=fmask)
+        y = self.model(c)
+        loss = self.crit(x, y)
+        self.opt.zero_grad()
+        loss.backward()
+        n = torch.nn.utils.clip_grad_norm_(self.model.parameters(), 1)
+        self.opt.step()
+        se = ((x - y) ** 2).detach()
+        return {"loss": float(loss), "grad_norm": float(n), "sq_full": float(se.sum()),
+                "sq_partial": float(((1 - fmask) * se).sum()), "y": y.detach().cpu().numpy()}
+
+    def evaluate(self, x, fmask):
+        x = torch.tensor(x, device=DEV); fmask = torch.tensor(fmask, device=DEV)
+        y = self.model(self.model.corrupt(input_data=x, mask=fmask))
+        se = ((x - y) ** 2).detach()
+        return {"y": y.detach().cpu().numpy(), "sq_full": float(se.sum()), "sq_partial": float(((1 - fmask) * se).sum())}
+
+
+@pytest.mark.parametrize("name", ["embedding_square", "embedding_taper"])
+def test_dropin_model_replays_reference_run(name):
+    g = Golden(name)
+    ad = DropInEmbeddingAdapter(g)
+    assert ad.init_matches, "same torch seed must reproduce the reference's initial weights bit for bit"
+    book, steps, _ = replay_embedding(g, ad)
+    assert close(steps["loss"], g["step_loss"]), max_err(steps["loss"], g["step_loss"])
+    assert close(steps["grad_norm"], g["step_grad_norm"])
+    for k in ("ftl", "ptl", "fvl", "pvl", "rl"):
+        assert close(book[k], g["book_" + k]), (k, book[k], g["book_" + k])
+    sd = ad.model.state_dict()
+    for n in g.names:
+        assert close(sd[n].cpu().numpy(), g["final__" + n.replace(".", "__")]), n
+    assert "codae.hip" in str(type(ad.model._engine).__module__)
+
+
+class DropInAbaloneAdapter:
+    def __init__(self, g):
+        from codae.model import MixedVariableDenoisingAutoencoder
+        from codae.tool import CombinedCriterion
+        m = g.meta
+        torch.manual_seed(m["seed"])
+        self.model = MixedVariableDenoisingAutoencoder(m["arch"], 11, 11, torch.device(DEV), 2, 2, True)
+        self.init_matches = all(np.array_equal(p.detach().numpy(), g["init__" + n.replace(".", "__")])
+                                for n, p in self.model.state_dict().items())
+        self.model.to(DEV)
+        self.opt = torch.optim.Adam(self.model.parameters(), lr=m["lr"], weight_decay=m["weight_decay"])
+        self.crit = CombinedCriterion(arch=m["arch"], k_max=m["k_max"], device=torch.device(DEV),
+                                      observation_mask=torch.tensor(g["type_mask"]), weight=m["weight"], reduction="mean")
+
+    def step(self, x, fmask):
+        x = torch.tensor(x, device=DEV); fmask = torch.tensor(fmask, device=DEV)
+        y = self.model(self.model.corrupt(input_data=x, mask=fmask))
+        loss = self.crit(x=x, y=y)
+        self.opt.zero_grad()
+        loss.backward()
+        n = torch.nn.utils.clip_grad_norm_(self.model.parameters(), 1)
+        self.opt.step()
+        return {"loss": float(loss), "grad_norm": float(n), "y": y.detach().cpu().numpy()}
+
+    def evaluate(self, x, fmask):
+        x = torch.tensor(x, device=DEV); fmask = torch.tensor(fmask, device=DEV)
+        return {"y": self.model(self.model.corrupt(input_data=x, mask=fmask)).detach().cpu().numpy()}
+
+
+def test_dropin_abalone_replays_reference_run():
+    """11-wide layers: every GEMM runs on the exact-fp32 MFMA kernel with ragged tiles."""
+    g = Golden("abalone_k2")
+    ad = DropInAbaloneAdapter(g)
+    assert ad.init_matches
+    book, steps = replay_abalone(g, ad)
+    assert close(steps["loss"], g["step_loss"]), max_err(steps["loss"], g["step_loss"])
+    assert close(steps["grad_norm"], g["step_grad_norm"])
+    for k in ("ftl", "ptl", "fvl", "pvl"):
+        assert close(book[k], g["book_" + k]), k
+    for k in ("ftl_per_k", "ptl_per_k", "fvl_per_k", "pvl_per_k"):
+        assert close(np.stack(book[k]), g["book_" + k]), k
+    sd = ad.model.state_dict()
+    for n in g.names:
+        assert close(sd[n].cpu().numpy(), g["final__" + n.replace(".", "__")]), n
+
+
+def _oracle_vs_engine(precision, S, E, B, steps, tol):
+    """Seeded synthetic run at a size the oracle finishes in seconds: fused HIP step vs oracle."""
+    from codae.train import HipEmbeddingTrainer
+    from oracle import dae_oracle as O
+    io = S * E
+    rng = np.random.default_rng(42)
+    N = 4 * B
+    data = rng.random((N, io), dtype=np.float32)
+    data = data / (data.max() - data.min())
+    sched = O.layer_schedule(io, io, 4, 4, False, "embedding")
+    params = O.init_params(sched, rng)
+    arch = [{"size": E, "position": s * E} for s in range(S)]
+    bm, nmr, _ = O.corrupter_tables(arch, 1)
+    mtu = np.stack([rng.permutation(S) for _ in range(N)])
+    lr, wd = 1e-3, 1e-4
+    tr = HipEmbeddingTrainer(sched, torch.tensor(data), torch.tensor(bm).to(torch.uint8), torch.tensor(mtu).to(torch.int32),
+                             lr, wd, 1.0, max_batch=B, precision=precision, device=DEV)
+    tr.load_params(params)
+    orc = O.EmbeddingTrainer(params, [r for _, _, r in sched], lr, wd)
+    for s in range(steps):
+        idx = rng.permutation(N)[:B]
+        _, fmask = O.get_masks(bm, nmr, mtu, 1, idx, 0)
+        ro = orc.step(data[idx], fmask)
+        tr.engine.zero_metric_sums()
+        tr.train_batch(torch.tensor(idx, dtype=torch.int32, device=DEV), run=0)
+        sq, sqp, gsq, loss = tr.engine.read_scalars()
+        assert abs(loss - float(ro["loss"])) <= tol * abs(float(ro["loss"])), (s, loss, ro["loss"])
+        assert abs(math.sqrt(gsq) - float(ro["grad_norm"])) <= 5 * tol * float(ro["grad_norm"]), (s, math.sqrt(gsq), ro["grad_norm"])
+        assert abs(sqp - float(ro["sq_partial"])) <= tol * float(ro["sq_partial"])
+    return tr, orc
+
+
+def test_fused_f32_vs_oracle_3x128_batch1024():
+    tr, orc = _oracle_vs_engine("f32", 3, 128, 1024, 3, 1e-3)
+    for l, (w, b) in enumerate(orc.params):
+        assert close(tr.engine.weight(l).cpu().numpy(), w)
+        assert close(tr.engine.bias(l).cpu().numpy(), b)
+
+
+def test_fused_bf16_vs_oracle_3x128_batch1024():
+    """bf16 operands, fp32 accumulate: loss / grad-norm within 2 % of the fp32 oracle (stated
+    tolerance of the throughput mode); parameters move by lr-sized Adam steps either way."""
+    tr, orc = _oracle_vs_engine("bf16", 3, 128, 1024, 3, 2e-2)
+    for l, (w, b) in enumerate(orc.params):
+        assert np.allclose(tr.engine.weight(l).cpu().numpy(), w, rtol=0, atol=2.5e-3)   # <= 2 Adam steps apart
+
+
+def test_fused_bf16_ragged_batch():
+    """partial last batch (B not a multiple of 64): zero-padded rows must not leak into gradients."""
+    tr, orc = _oracle_vs_engine("bf16", 3, 64, 200, 2, 2e-2)
+
+
+def test_engine_rejects_bad_shapes():
+    from codae.hip import HipError
+    from codae.hip.engine import DaeEngine
+    with pytest.raises(HipError):
+        DaeEngine([(11, 11, True), (11, 11, False)], 64, "bf16", DEV)      # widths not % 64
+    eng = DaeEngine([(11, 11, True), (11, 11, False)], 64, "f32", DEV)
+    with pytest.raises(HipError):
+        eng.forward(torch.zeros(65, 11, device=DEV))                         # batch > max_batch
+    with pytest.raises(HipError):
+        eng.forward(torch.zeros(4, 12, device=DEV))                          # wrong width
