@@ -141,7 +141,12 @@ class DaeEngine:
             raise HipError("mask_table must be a uint8 tensor on %s" % self.device)
         if B is None:
             B = int(row_idx.numel()) if row_idx is not None else int(data.shape[0])
-        return Batch(ptr(data), ptr(row_idx), ptr(mask_id), ptr(mask_table), int(B), int(data.shape[1]))
+        b = Batch(ptr(data), ptr(row_idx), ptr(mask_id), ptr(mask_table), int(B), int(data.shape[1]))
+        # the struct only carries raw pointers: pin the tensors to it, or a temporary (mask_id) is
+        # returned to the caching allocator and handed to the next torch.empty() while the kernels
+        # that read it are still queued
+        b._pinned = (data, row_idx, mask_id, mask_table)
+        return b
 
     def hyper(self, lr, weight_decay, clip=1.0, global_rows=0, betas=(0.9, 0.999), eps=1e-8, step=None):
         return Hyper(lr, weight_decay, betas[0], betas[1], eps, clip if clip else 0.0,

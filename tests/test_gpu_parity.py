@@ -244,8 +244,14 @@ def test_fused_bf16_vs_oracle_3x128_batch1024():
     """bf16 operands, fp32 accumulate: loss / grad-norm within 2 % of the fp32 oracle (stated
     tolerance of the throughput mode); parameters move by lr-sized Adam steps either way."""
     tr, orc = _oracle_vs_engine("bf16", 3, 128, 1024, 3, 2e-2)
+    lr, steps = 1e-3, 3
     for l, (w, b) in enumerate(orc.params):
-        assert np.allclose(tr.engine.weight(l).cpu().numpy(), w, rtol=0, atol=2.5e-3)   # <= 2 Adam steps apart
+        d = np.abs(tr.engine.weight(l).cpu().numpy() - w)
+        # Adam normalises every element's step to ~lr, so an element whose gradient is within bf16
+        # noise of zero can move the other way: at most 2*lr apart per step, and only a few do
+        assert d.max() <= 2 * lr * steps + 1e-6, (l, d.max())
+        assert np.median(d) < 2e-5, (l, np.median(d))
+        assert (d > lr).mean() < 0.02, (l, (d > lr).mean())
 
 
 def test_fused_bf16_ragged_batch():
