@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training samples/s of the DAE hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[2], SURVEY.md 8d "C3"): embedding.yaml topology — 3 slots x 512
+(io 1536), z = io, 4+4 hidden layers, steep False => 10 x Linear(1536,1536); batch 8192 rows PER
+GPU (weak scaling); bf16 operands / fp32 accumulate; Adam lr 1e-5, wd 1e-4, clip 1.0
+(config/embedding.yaml:8-11 of the reference).  Synthetic inputs: dataset[16*B, io] U[0,1) from
+default_rng(1234) scaled by (max-min); per-row blanked slot from default_rng(5678); Xavier
+weights from seed 0.  The dataset, mask tables and all per-step index vectors are resident in HBM
+before the timed region; a step is one call of the fused C-ABI step (gather+corrupt, 10 forward
+GEMMs, MSE loss+grad+metric sums, 10 weight-gradient + 9 data-gradient GEMMs, grad-norm clip,
+Adam + bf16 shadow refresh); with N > 1 the gradient buckets are all-reduced over RCCL between
+backward and update, overlapped with the remaining backward GEMMs.
+
+One JSON line on rank 0.  `roofline`: the GEMM class that takes the most time per step, timed
+with hipEvent pairs recorded around every launch of the timed region on the launch stream
+(codae_profile_begin/_end); achieved = 2*M*N*K / mean launch time.  `cpu_baseline`: the numpy
+oracle (oracle/dae_oracle.py, a port of the reference's math; used here only as the thing timed)
+on the host cores, bounded sample.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "mui-deepautoencoder_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+S, E, BATCH = 3, 512, 8192
+N_IN, N_OUT = 4, 4
+LR, WD, CLIP = 1e-5, 1e-4, 1.0
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_F32_TFLOPS = 157.3
+
+
+def square_schedule(io, nb_in, nb_out):
+    """z = io, steep False => inc 0 => (nb_in + nb_out + 2) square Linears, ReLU after all but the
+    code layer and the output layer (embedding_denoising_autoencoder.py:59-126)."""
+    relu = [True] * nb_in + [False] + [True] * nb_out + [False]
+    return [(io, io, r) for r in relu]
+
+
+def flops_per_sample(schedule):
+    """2 * (3 * sum K_l N_l - K_1 N_1): forward + wgrad for every layer, dgrad for all but the first."""
+    tot = sum(k * n for k, n, _ in schedule)
+    return 2 * (3 * tot - schedule[0][0] * schedule[0][1])
+
+
+def make_inputs(n_rows, io, slots):
+    import numpy as np
+    rng = np.random.default_rng(1234)
+    data = rng.random((n_rows, io), dtype=np.float32)
+    data /= (data.max() - data.min())
+    blank = np.random.default_rng(5678).integers(0, slots, size=n_rows)
+    return data, blank.astype(np.int32)
+
+
+def cpu_baseline(schedule, data, blank, io, slots, budget_s=18.0):
+    """Time the oracle's training step (numpy, BLAS threads = host cores given to this process)."""
+    import numpy as np
+    from oracle import dae_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([d.get("num_threads", 1) for d in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    rng = np.random.default_rng(0)
+    params = O.init_params(schedule, rng)
+    tr = O.EmbeddingTrainer(params, [r for _, _, r in schedule], LR, WD)
+    arch = [{"size": io // slots, "position": s * (io // slots)} for s in range(slots)]
+    bm, _, _ = O.corrupter_tables(arch, 1)
+    B = BATCH
+    x = data[:B]
+    fmask = bm[blank[:B]]
+    t0 = time.perf_counter()
+    tr.step(x, fmask)                      # warm-up (BLAS thread pool, page faults)
+    warm = time.perf_counter() - t0
+    n, t_sum = 0, 0.0
+    while n < 2 or (t_sum + warm < budget_s and n < 20):
+        t0 = time.perf_counter()
+        tr.step(x, fmask)
+        t_sum += time.perf_counter() - t0
+        n += 1
+        if t_sum > 2 * budget_s:
+            break
+    return {"value": B * n / t_sum, "unit": "samples/s", "cores": int(threads), "kind": "port",
+            "sample": "%d timed steps (1 warm-up) of the numpy oracle step at the same 3x512 / batch %d workload, fp32"
+                      % (n, B),
+            "ms_per_step": 1e3 * t_sum / n}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--slots", type=int, default=S)
+    ap.add_argument("--embedding", type=int, default=E)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not record per-launch hipEvents in the timed region (roofline then null)")
+    ap.add_argument("--buckets", type=int, default=4)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (libcodae_hip.so has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from codae.train import HipEmbeddingTrainer
+
+    slots, emb, B = args.slots, args.embedding, args.batch
+    io = slots * emb
+    schedule = square_schedule(io, N_IN, N_OUT)
+    n_rows = 16 * B
+    data, blank = make_inputs(n_rows, io, slots)
+
+    # Corrupter tables for k_max = 1: mask s blanks slot s; run 0 only (train_dae_on_embedding.py:198)
+    table = np.ones((slots, io), dtype=np.uint8)
+    for s_ in range(slots):
+        table[s_, s_ * emb:(s_ + 1) * emb] = 0
+    mask_to_use = torch.from_numpy(blank.reshape(-1, 1).copy())
+
+    tr = HipEmbeddingTrainer(schedule, torch.from_numpy(data), torch.from_numpy(table), mask_to_use, LR, WD, CLIP,
+                             max_batch=B, precision=args.precision, device=dev, distributed=distributed,
+                             n_buckets=args.buckets)
+    tr.init_params(seed=0)
+
+    # per-step row indices, resident before timing: one permutation of the dataset per epoch, the
+    # global batch of a step split into contiguous per-rank shards
+    total_steps = args.warmup + args.steps
+    g = torch.Generator(device="cpu").manual_seed(1)
+    steps_per_epoch = max(1, n_rows // (B * world))
+    idx_steps = []
+    perm = None
+    for st in range(total_steps):
+        if st % steps_per_epoch == 0:
+            perm = torch.randperm(n_rows, generator=g)
+        o = (st % steps_per_epoch) * B * world + rank * B
+        idx_steps.append(perm[o:o + B].to(torch.int32).to(dev))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for st in range(args.warmup):
+        tr.train_batch(idx_steps[st], run=0)
+    barrier()
+    kernel_events = not args.no_kernel_events
+    if kernel_events:
+        tr.engine.profile_begin(("gemm_fwd", "gemm_dgrad", "gemm_wgrad"), max_records=32 * args.steps + 64)
+    t0 = time.perf_counter()
+    for st in range(args.warmup, total_steps):
+        tr.train_batch(idx_steps[st], run=0)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = tr.engine.profile_end() if kernel_events else {}
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if distributed:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    loss, gnorm = tr.last_loss_and_grad_norm()
+
+    if rank == 0:
+        fps = flops_per_sample(schedule)
+        value = B * world * args.steps / elapsed
+        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+        out = {
+            "metric": "training samples/sec at 3x512-dim input, batch 8192" if (slots, emb, B) == (S, E, BATCH)
+                      else "training samples/sec at %dx%d-dim input, batch %d" % (slots, emb, B),
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "embedding.yaml topology: %d slots x %d (io %d), z=io, 4+4 layers -> 10 x Linear(%d,%d); "
+                                   "batch %d rows per GPU, Adam lr 1e-5 wd 1e-4 clip 1.0, slot-blanking k=1"
+                                   % (slots, emb, io, io, io, B),
+                       "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "step_tflops_algorithmic": fps * B / 1e12,
+                       "mfma_roofline_frac_whole_step": (fps * value / world) / (peak * 1e12)},
+            "final_loss": loss, "final_grad_norm": gnorm,
+        }
+        roof = None
+        if prof:
+            by = {}
+            gemm_flops = 2.0 * B * io * io
+            for name, ms in prof.items():
+                mean_ms = float(np.mean(ms))
+                by[name] = {"launches": len(ms), "mean_ms": mean_ms, "min_ms": float(np.min(ms)),
+                            "tflops": gemm_flops / (mean_ms * 1e-3) / 1e12,
+                            "ms_per_step": float(np.sum(ms)) / args.steps}
+            dom = max(by, key=lambda k: by[k]["ms_per_step"])
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+            if os.path.exists(tfile):
+                try:
+                    traffic = json.load(open(tfile)).get(dom)
+                except Exception:
+                    traffic = None
+            roof = {"bound": "mfma", "kernel": dom, "achieved": by[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
+                    "frac": by[dom]["tflops"] / peak, "traffic": traffic,
+                    "flops_per_launch": gemm_flops, "by_kernel": by}
+        out["roofline"] = roof
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(schedule, data, blank, io, slots)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

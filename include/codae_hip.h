@@ -105,6 +105,11 @@ typedef struct {
     const uint8_t* mask_table; /* [n_masks][io] 0/1 = Corrupter.binary_masks (data_tool.py:202-209) */
     int32_t B;
     int32_t io;
+    /* alternative to mask_id: look the id up on the device, id = mask_to_use[row * nb_run + run]
+     * with row = row_idx[b] (Corrupter.mask_to_use, data_tool.py:222-226); used when mask_id is NULL */
+    const int32_t* mask_to_use;
+    int32_t nb_run;
+    int32_t run;
 } codae_batch;
 
 typedef struct {
@@ -157,6 +162,26 @@ int codae_train_step(codae_handle h, const codae_buffers* bufs, const codae_batc
 /* validation body (:245-258): forward + metric sums only */
 int codae_eval_step(codae_handle h, const codae_buffers* bufs, const codae_batch* batch, float* out_y,
                     void* stream);
+
+/* ---- per-kernel timing (bench.py roofline leg) ------------------------------ */
+/* kernel classes recorded by the engine's step/forward/backward entry points */
+enum {
+    CODAE_K_GEMM_FWD = 0,   /* y = act(x W^T + b) */
+    CODAE_K_GEMM_DGRAD = 1, /* dx = (dy W) * relu' */
+    CODAE_K_GEMM_WGRAD = 2, /* dW = dy^T x (the GEMM launch only) */
+    CODAE_K_LOSS = 3,
+    CODAE_K_GATHER = 4,
+    CODAE_K_SUMSQ = 5,
+    CODAE_K_ADAM = 6,
+    CODAE_K_SLAB_REDUCE = 7,
+    CODAE_K_COUNT = 8
+};
+/* Start recording a hipEvent pair around every launch whose class bit is set in class_mask
+ * (bit k = CODAE_K_k), on the stream the launch uses; at most max_records pairs are kept. */
+int codae_profile_begin(codae_handle h, uint32_t class_mask, int32_t max_records);
+/* Stop recording, wait for the recorded events and return per record the class and the elapsed
+ * milliseconds.  n_out receives the number of records written (<= capacity). */
+int codae_profile_end(codae_handle h, int32_t* kinds, float* ms, int32_t capacity, int32_t* n_out);
 
 /* ---- stand-alone ops (also used by the drop-in classes) ------------------- */
 /* model.corrupt(input, mask) = input.clone()*mask (embedding_...py:226-239) */

@@ -14,6 +14,7 @@ PREC_F32 = 0
 PREC_BF16 = 1
 
 S_SQ_FULL, S_SQ_PARTIAL, S_GRAD_SQ, S_LAST_LOSS, S_STEP_SQ, S_COUNT = 0, 1, 2, 3, 4, 8
+KERNEL_CLASSES = ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "loss", "gather", "sumsq", "adam", "slab_reduce")
 
 
 class HipError(RuntimeError):
@@ -42,7 +43,8 @@ class Buffers(C.Structure):
 
 class Batch(C.Structure):
     _fields_ = [("data", C.c_void_p), ("row_idx", C.c_void_p), ("mask_id", C.c_void_p),
-                ("mask_table", C.c_void_p), ("B", C.c_int32), ("io", C.c_int32)]
+                ("mask_table", C.c_void_p), ("B", C.c_int32), ("io", C.c_int32),
+                ("mask_to_use", C.c_void_p), ("nb_run", C.c_int32), ("run", C.c_int32)]
 
 
 class Hyper(C.Structure):
@@ -69,6 +71,8 @@ PROTOTYPES = {
     "codae_step_update": (C.c_int, [_P, C.POINTER(Buffers), C.POINTER(Hyper), _P]),
     "codae_train_step": (C.c_int, [_P, C.POINTER(Buffers), C.POINTER(Batch), C.POINTER(Hyper), _P]),
     "codae_eval_step": (C.c_int, [_P, C.POINTER(Buffers), C.POINTER(Batch), _P, _P]),
+    "codae_profile_begin": (C.c_int, [_P, C.c_uint32, _I32]),
+    "codae_profile_end": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_float), _I32, C.POINTER(C.c_int32)]),
     "codae_corrupt": (C.c_int, [_P, _P, _P, _I64, _P]),
     "codae_expand_masks": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "codae_mse_loss_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _F, _P, _P]),

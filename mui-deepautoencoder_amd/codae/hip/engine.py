@@ -130,8 +130,9 @@ class DaeEngine:
         return dx
 
     # ---- fused step path --------------------------------------------------------------
-    def make_batch(self, data, row_idx, mask_id, mask_table, B=None):
-        """data [N,io] fp32; row_idx / mask_id int32 [B] or None; mask_table uint8 [n_masks, io] or None."""
+    def make_batch(self, data, row_idx, mask_id, mask_table, B=None, mask_to_use=None, run=0):
+        """data [N,io] fp32; row_idx / mask_id int32 [B] or None; mask_table uint8 [n_masks, io] or None;
+        mask_to_use int32 [N, nb_run] + run: device-side id lookup when mask_id is None."""
         if data.dtype != torch.float32 or not data.is_contiguous() or data.device != self.device:
             raise HipError("batch data must be a contiguous fp32 tensor on %s" % self.device)
         for name, t in (("row_idx", row_idx), ("mask_id", mask_id)):
@@ -141,11 +142,18 @@ class DaeEngine:
             raise HipError("mask_table must be a uint8 tensor on %s" % self.device)
         if B is None:
             B = int(row_idx.numel()) if row_idx is not None else int(data.shape[0])
-        b = Batch(ptr(data), ptr(row_idx), ptr(mask_id), ptr(mask_table), int(B), int(data.shape[1]))
+        nb_run = 0
+        if mask_to_use is not None:
+            if mask_to_use.dtype != torch.int32 or mask_to_use.device != self.device or not mask_to_use.is_contiguous() \
+                    or mask_to_use.dim() != 2 or mask_to_use.shape[0] != data.shape[0]:
+                raise HipError("mask_to_use must be a contiguous int32 [n_rows, nb_run] tensor on %s" % self.device)
+            nb_run = int(mask_to_use.shape[1])
+        b = Batch(ptr(data), ptr(row_idx), ptr(mask_id), ptr(mask_table), int(B), int(data.shape[1]),
+                  ptr(mask_to_use), nb_run, int(run))
         # the struct only carries raw pointers: pin the tensors to it, or a temporary (mask_id) is
         # returned to the caching allocator and handed to the next torch.empty() while the kernels
         # that read it are still queued
-        b._pinned = (data, row_idx, mask_id, mask_table)
+        b._pinned = (data, row_idx, mask_id, mask_table, mask_to_use)
         return b
 
     def hyper(self, lr, weight_decay, clip=1.0, global_rows=0, betas=(0.9, 0.999), eps=1e-8, step=None):
@@ -175,6 +183,26 @@ class DaeEngine:
     def eval_step(self, batch, out_y=None):
         with torch.cuda.device(self.device):
             check(self._lib.codae_eval_step(self._h, C.byref(self.bufs), C.byref(batch), ptr(out_y), current_stream()))
+
+    def profile_begin(self, classes=("gemm_fwd", "gemm_dgrad", "gemm_wgrad"), max_records=4096):
+        from . import KERNEL_CLASSES
+        mask = 0
+        for c in classes:
+            mask |= 1 << KERNEL_CLASSES.index(c)
+        self._prof_cap = int(max_records)
+        check(self._lib.codae_profile_begin(self._h, mask, self._prof_cap))
+
+    def profile_end(self):
+        """{class name: [milliseconds per launch]} (synchronises on the recorded events)."""
+        from . import KERNEL_CLASSES
+        kinds = (C.c_int32 * self._prof_cap)()
+        ms = (C.c_float * self._prof_cap)()
+        n = C.c_int32()
+        check(self._lib.codae_profile_end(self._h, kinds, ms, self._prof_cap, C.byref(n)))
+        out = {}
+        for i in range(n.value):
+            out.setdefault(KERNEL_CLASSES[kinds[i]], []).append(float(ms[i]))
+        return out
 
     def output_view(self, B):
         """fp32 [B, io] view of the reconstruction the last step left in the workspace."""

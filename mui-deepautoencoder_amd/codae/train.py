@@ -110,10 +110,10 @@ class HipEmbeddingTrainer:
 
     # ---- steps ---------------------------------------------------------------------------
     def _batch(self, row_idx, run):
-        mask_id = None
         if self.mask_to_use is not None and run is not None:
-            mask_id = self.mask_to_use[row_idx.long(), run].contiguous()
-        return self.engine.make_batch(self.data, row_idx, mask_id, self.mask_table)
+            # id = mask_to_use[row][run] is looked up inside the kernels
+            return self.engine.make_batch(self.data, row_idx, None, self.mask_table, mask_to_use=self.mask_to_use, run=run)
+        return self.engine.make_batch(self.data, row_idx, None, None)
 
     def train_batch(self, row_idx, run=0, mask_id=None):
         """One optimizer step on rows `row_idx` (int32 device tensor) of the resident dataset."""

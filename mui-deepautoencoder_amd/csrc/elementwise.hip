@@ -49,8 +49,11 @@ __global__ __launch_bounds__(NT) void gather_corrupt_kernel(const float* __restr
                                                             const int32_t* __restrict__ row_idx,
                                                             const int32_t* __restrict__ mask_id,
                                                             const uint8_t* __restrict__ table, int B, int io,
-                                                            void* __restrict__ out) {
+                                                            void* __restrict__ out,
+                                                            const int32_t* __restrict__ mask_to_use, int nb_run,
+                                                            int run) {
     constexpr int W = VEC ? 4 : 1;
+    const bool masked = (mask_id != nullptr) || (mask_to_use != nullptr);
     const int cols = io / W;
     const int64_t total = (int64_t)B * cols;
     for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < total; e += (int64_t)gridDim.x * NT) {
@@ -62,14 +65,18 @@ __global__ __launch_bounds__(NT) void gather_corrupt_kernel(const float* __restr
         if constexpr (VEC) {
             const float4 x = *reinterpret_cast<const float4*>(src);
             v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
-            if (mask_id) {
-                const uint32_t m = *reinterpret_cast<const uint32_t*>(table + (int64_t)mask_id[b] * io + c);
+            if (masked) {
+                const int id = mask_id ? mask_id[b] : mask_to_use[src_row * nb_run + run];
+                const uint32_t m = *reinterpret_cast<const uint32_t*>(table + (int64_t)id * io + c);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = ((m >> (8 * k)) & 0xff) ? v[k] : 0.f;
             }
         } else {
             v[0] = src[0];
-            if (mask_id) v[0] = table[(int64_t)mask_id[b] * io + c] ? v[0] : 0.f;
+            if (masked) {
+                const int id = mask_id ? mask_id[b] : mask_to_use[src_row * nb_run + run];
+                v[0] = table[(int64_t)id * io + c] ? v[0] : 0.f;
+            }
         }
         const int64_t o = (int64_t)b * io + c;
         if constexpr (OUT_BF16) {
@@ -140,8 +147,10 @@ __global__ __launch_bounds__(NT) void mse_loss_kernel(const float* __restrict__ 
                                                       const uint8_t* __restrict__ table, int B, int io,
                                                       const float* __restrict__ y, void* __restrict__ dy,
                                                       float inv_n, float* __restrict__ colsum,
-                                                      double* __restrict__ scalars, int want_grad) {
+                                                      double* __restrict__ scalars, int want_grad,
+                                                      const int32_t* __restrict__ mask_to_use, int nb_run, int run) {
     __shared__ float red[4];
+    const bool masked = (mask_id != nullptr) || (mask_to_use != nullptr);
     constexpr int W = VEC ? 4 : 1;
     const int cols = io / W;
     const int r_begin = blockIdx.x * LOSS_ROWS;
@@ -154,16 +163,17 @@ __global__ __launch_bounds__(NT) void mse_loss_kernel(const float* __restrict__ 
             const int64_t src_row = row_idx ? row_idx[b] : b;
             float xv[4], yv[4];
             uint32_t m = 0x01010101u;
+            const int id = !masked ? 0 : (mask_id ? mask_id[b] : mask_to_use[src_row * nb_run + run]);
             if constexpr (VEC) {
                 const float4 x4 = *reinterpret_cast<const float4*>(data + src_row * io + c);
                 const float4 y4 = *reinterpret_cast<const float4*>(y + (int64_t)b * io + c);
                 xv[0] = x4.x; xv[1] = x4.y; xv[2] = x4.z; xv[3] = x4.w;
                 yv[0] = y4.x; yv[1] = y4.y; yv[2] = y4.z; yv[3] = y4.w;
-                if (mask_id) m = *reinterpret_cast<const uint32_t*>(table + (int64_t)mask_id[b] * io + c);
+                if (masked) m = *reinterpret_cast<const uint32_t*>(table + (int64_t)id * io + c);
             } else {
                 xv[0] = data[src_row * io + c];
                 yv[0] = y[(int64_t)b * io + c];
-                if (mask_id) m = table[(int64_t)mask_id[b] * io + c];
+                if (masked) m = table[(int64_t)id * io + c];
             }
             float g[4];
 #pragma unroll
@@ -198,7 +208,7 @@ __global__ __launch_bounds__(NT) void mse_loss_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) {
         atomicAdd(&scalars[CODAE_S_SQ_FULL], (double)bsq);
         atomicAdd(&scalars[CODAE_S_STEP_SQ], (double)bsq);
-        if (mask_id) atomicAdd(&scalars[CODAE_S_SQ_PARTIAL], (double)bsqp);
+        if (masked) atomicAdd(&scalars[CODAE_S_SQ_PARTIAL], (double)bsqp);
     }
 }
 
@@ -330,12 +340,15 @@ inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) ==
 
 int launch_gather_corrupt(const codae_batch* b, void* out, int out_bf16, hipStream_t s) {
     CODAE_REQUIRE(b && b->data && out && b->B > 0 && b->io > 0, "gather_corrupt: bad batch");
-    CODAE_REQUIRE(!b->mask_id || b->mask_table, "gather_corrupt: mask_id without mask_table");
-    const bool vec = (b->io % 4 == 0) && a16(b->data) && a16(out) && (!b->mask_id || (reinterpret_cast<uintptr_t>(b->mask_table) & 3) == 0);
+    const bool masked = b->mask_id || b->mask_to_use;
+    CODAE_REQUIRE(!masked || b->mask_table, "gather_corrupt: mask ids without mask_table");
+    CODAE_REQUIRE(!b->mask_to_use || b->mask_id || (b->nb_run > 0 && b->run >= 0 && b->run < b->nb_run),
+                  "gather_corrupt: run %d outside [0, %d)", b->run, b->nb_run);
+    const bool vec = (b->io % 4 == 0) && a16(b->data) && a16(out) && (!masked || (reinterpret_cast<uintptr_t>(b->mask_table) & 3) == 0);
     const int64_t items = (int64_t)b->B * (vec ? b->io / 4 : b->io);
     const int grid = grid_for(items);
 #define GC(V, O) hipLaunchKernelGGL((gather_corrupt_kernel<V, O>), dim3(grid), dim3(NT), 0, s, b->data, b->row_idx, \
-                                    b->mask_id, b->mask_table, b->B, b->io, out)
+                                    b->mask_id, b->mask_table, b->B, b->io, out, b->mask_to_use, b->nb_run, b->run)
     if (vec && out_bf16) GC(true, true);
     else if (vec) GC(true, false);
     else if (out_bf16) GC(false, true);
@@ -380,11 +393,14 @@ int launch_mse_loss(const codae_batch* b, const float* y, void* dy, int dy_bf16,
                     double* scalars, int want_grad, hipStream_t s) {
     CODAE_REQUIRE(b && b->data && y && scalars && b->B > 0 && b->io > 0, "mse_loss: bad args");
     CODAE_REQUIRE(!want_grad || dy, "mse_loss: gradient requested without dy");
+    const bool masked = b->mask_id || b->mask_to_use;
+    CODAE_REQUIRE(!masked || b->mask_table, "mse_loss: mask ids without mask_table");
     const bool vec = (b->io % 4 == 0) && a16(b->data) && a16(y) && (!dy || a16(dy)) &&
-                     (!b->mask_id || (reinterpret_cast<uintptr_t>(b->mask_table) & 3) == 0);
+                     (!masked || (reinterpret_cast<uintptr_t>(b->mask_table) & 3) == 0);
     const int grid = (b->B + LOSS_ROWS - 1) / LOSS_ROWS;
 #define ML(V, O) hipLaunchKernelGGL((mse_loss_kernel<V, O>), dim3(grid), dim3(NT), 0, s, b->data, b->row_idx, \
-                                    b->mask_id, b->mask_table, b->B, b->io, y, dy, inv_n, colsum, scalars, want_grad)
+                                    b->mask_id, b->mask_table, b->B, b->io, y, dy, inv_n, colsum, scalars, want_grad, \
+                                    b->mask_to_use, b->nb_run, b->run)
     if (vec && dy_bf16) ML(true, true);
     else if (vec) ML(true, false);
     else if (dy_bf16) ML(false, true);

@@ -38,11 +38,34 @@ struct codae_engine {
     std::vector<int64_t> act_off;  // byte offsets of act[0..L-1] and y (index L) inside bufs->acts
     int64_t act_bytes = 0, dact_one = 0, slab_bytes = 0;
     std::vector<int> split_k;
+    // optional per-launch hipEvent pairs (codae_profile_begin / _end)
+    mutable bool prof_on = false;
+    mutable uint32_t prof_mask = 0;
+    mutable int prof_n = 0;
+    mutable std::vector<hipEvent_t> prof_start, prof_stop;
+    mutable std::vector<int> prof_kind;
     int esize() const { return prec == CODAE_PREC_BF16 ? 2 : 4; }
     int rows_for(int B) const { return prec == CODAE_PREC_BF16 ? (int)round_up(B, 64) : B; }
 };
 
 namespace {
+
+// records a start/stop event pair around the launches made while it is alive
+struct ProfScope {
+    const codae_engine* e;
+    hipStream_t s;
+    int slot = -1;
+    ProfScope(const codae_engine* e_, int kind, hipStream_t s_) : e(e_), s(s_) {
+        if (e->prof_on && ((e->prof_mask >> kind) & 1u) && e->prof_n < (int)e->prof_start.size()) {
+            slot = e->prof_n++;
+            e->prof_kind[slot] = kind;
+            (void)hipEventRecord(e->prof_start[slot], s);
+        }
+    }
+    ~ProfScope() {
+        if (slot >= 0) (void)hipEventRecord(e->prof_stop[slot], s);
+    }
+};
 
 int choose_split_k(int N, int K, int rows) {
     const char* env = getenv("CODAE_WGRAD_SPLITK");
@@ -79,6 +102,7 @@ int check_common(codae_handle h, const codae_buffers* b, int B) {
 int run_linear(const codae_engine* e, const codae_buffers* b, int l, const void* x, void* y, bool y_f32, int rows,
                hipStream_t s) {
     const int N = e->out[l], K = e->in[l];
+    ProfScope prof(e, CODAE_K_GEMM_FWD, s);
     if (e->prec == CODAE_PREC_BF16) {
         GemmBf16 g{};
         g.A = reinterpret_cast<const bf16_t*>(x); g.lda = K; g.a_mode = OP_KC;
@@ -112,13 +136,20 @@ int run_wgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, hi
         if (S > 1) {
             CODAE_REQUIRE(b->slabs != nullptr, "bf16 wgrad needs the slab workspace");
             g.C = b->slabs;
-            int rc = gemm_bf16(g, s);
+            int rc;
+            {
+                ProfScope prof(e, CODAE_K_GEMM_WGRAD, s);
+                rc = gemm_bf16(g, s);
+            }
             if (rc) return rc;
+            ProfScope prof(e, CODAE_K_SLAB_REDUCE, s);
             return launch_reduce_slabs(reinterpret_cast<const float*>(b->slabs), S, (int64_t)N * K, dW, (int64_t)N * K, s);
         }
         g.C = dW;
+        ProfScope prof(e, CODAE_K_GEMM_WGRAD, s);
         return gemm_bf16(g, s);
     }
+    ProfScope prof(e, CODAE_K_GEMM_WGRAD, s);
     GemmF32 g{};
     g.A = reinterpret_cast<const float*>(dact_ptr(e, b, l)); g.a_rs = 1; g.a_ks = N;
     g.B = reinterpret_cast<const float*>(act_ptr(e, b, l)); g.b_rs = 1; g.b_ks = K;
@@ -131,6 +162,7 @@ int run_wgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, hi
 int run_dgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, float* dx_f32, hipStream_t s) {
     const int N = e->out[l], K = e->in[l];
     const bool to_dx = (dx_f32 != nullptr);
+    ProfScope prof(e, CODAE_K_GEMM_DGRAD, s);
     if (e->prec == CODAE_PREC_BF16) {
         GemmBf16 g{};
         g.A = reinterpret_cast<const bf16_t*>(dact_ptr(e, b, l)); g.lda = N; g.a_mode = OP_KC;
@@ -263,8 +295,43 @@ int codae_create(const codae_spec* spec, codae_handle* out) {
     return CODAE_OK;
 }
 
+static void profile_release(codae_handle h) {
+    for (hipEvent_t ev : h->prof_start) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : h->prof_stop) (void)hipEventDestroy(ev);
+    h->prof_start.clear(); h->prof_stop.clear(); h->prof_kind.clear();
+    h->prof_on = false; h->prof_n = 0;
+}
+
 int codae_destroy(codae_handle h) {
+    if (h) profile_release(h);
     delete h;
+    return CODAE_OK;
+}
+
+int codae_profile_begin(codae_handle h, uint32_t class_mask, int32_t max_records) {
+    CODAE_REQUIRE(h && max_records > 0 && max_records <= (1 << 20), "codae_profile_begin: bad arguments");
+    profile_release(h);
+    h->prof_start.resize(max_records); h->prof_stop.resize(max_records); h->prof_kind.assign(max_records, -1);
+    for (int i = 0; i < max_records; ++i) {
+        CODAE_HIP_CHECK(hipEventCreate(&h->prof_start[i]));
+        CODAE_HIP_CHECK(hipEventCreate(&h->prof_stop[i]));
+    }
+    h->prof_mask = class_mask; h->prof_n = 0; h->prof_on = true;
+    return CODAE_OK;
+}
+
+int codae_profile_end(codae_handle h, int32_t* kinds, float* ms, int32_t capacity, int32_t* n_out) {
+    CODAE_REQUIRE(h && kinds && ms && n_out, "codae_profile_end: null argument");
+    h->prof_on = false;
+    int n = h->prof_n < capacity ? h->prof_n : capacity;
+    for (int i = 0; i < n; ++i) {
+        CODAE_HIP_CHECK(hipEventSynchronize(h->prof_stop[i]));
+        float t = 0.f;
+        CODAE_HIP_CHECK(hipEventElapsedTime(&t, h->prof_start[i], h->prof_stop[i]));
+        kinds[i] = h->prof_kind[i]; ms[i] = t;
+    }
+    *n_out = n;
+    profile_release(h);
     return CODAE_OK;
 }
 
@@ -359,7 +426,10 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
     const int B = batch->B, L = h->L;
     const int rows = h->rows_for(B);
     const bool bf = h->prec == CODAE_PREC_BF16;
-    rc = launch_gather_corrupt(batch, act_ptr(h, b, 0), bf, s);
+    {
+        ProfScope prof(h, CODAE_K_GATHER, s);
+        rc = launch_gather_corrupt(batch, act_ptr(h, b, 0), bf, s);
+    }
     if (rc) return rc;
     rc = zero_pad_rows(h, act_ptr(h, b, 0), B, rows, h->in[0], s);
     if (rc) return rc;
@@ -376,8 +446,11 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
         const double n_glob = (double)(hyper->loss_scale_rows > 0.f ? hyper->loss_scale_rows : (float)B) * batch->io;
         rc = zero_pad_rows(h, dact_ptr(h, b, L - 1), B, rows, batch->io, s);
         if (rc) return rc;
-        rc = launch_mse_loss(batch, y, dact_ptr(h, b, L - 1), bf, (float)(1.0 / n_glob), b->grads + h->b_off[L - 1],
-                             b->scalars, 1, s);
+        {
+            ProfScope prof(h, CODAE_K_LOSS, s);
+            rc = launch_mse_loss(batch, y, dact_ptr(h, b, L - 1), bf, (float)(1.0 / n_glob), b->grads + h->b_off[L - 1],
+                                 b->scalars, 1, s);
+        }
         if (rc) return rc;
         return launch_finish_loss(b->scalars, 1.0 / ((double)B * batch->io), s);
     }
@@ -404,9 +477,11 @@ int codae_step_update(codae_handle h, const codae_buffers* b, const codae_hyper*
     hipStream_t s = (hipStream_t)stream;
     if (hyper->max_grad_norm > 0.f) {
         CODAE_HIP_CHECK(hipMemsetAsync(b->scalars + CODAE_S_GRAD_SQ, 0, sizeof(double), s));
+        ProfScope prof(h, CODAE_K_SUMSQ, s);
         int rc = launch_sumsq(b->grads, h->n_param, b->scalars + CODAE_S_GRAD_SQ, s);
         if (rc) return rc;
     }
+    ProfScope prof(h, CODAE_K_ADAM, s);
     bf16_t* shadow = h->prec == CODAE_PREC_BF16 ? reinterpret_cast<bf16_t*>(b->shadow_w) : nullptr;
     CODAE_REQUIRE(h->prec != CODAE_PREC_BF16 || shadow, "codae_step_update: shadow_w missing");
     return launch_clip_adam(b->params, b->grads, b->adam_m, b->adam_v, h->n_param, hyper, b->scalars + CODAE_S_GRAD_SQ,
