@@ -63,6 +63,13 @@ class DataParallel:
         for w in works:
             w.wait()
 
+    def train_step(self, batch, hyper, B):
+        """forward+loss -> bucketed backward with overlapped all-reduce -> clip+Adam.
+        `hyper.loss_scale_rows` must hold the GLOBAL batch rows."""
+        self.engine.step_forward_loss(batch, hyper)
+        self.backward_and_reduce(B)
+        self.engine.step_update(hyper)
+
     def broadcast_params(self, params_flat):
         if self.world > 1:
             self.dist.broadcast(params_flat, src=0, group=self.group)
@@ -127,9 +134,7 @@ class HipEmbeddingTrainer:
         if self.dp is None:
             eng.train_step(batch, hyper)
         else:
-            eng.step_forward_loss(batch, hyper)
-            self.dp.backward_and_reduce(B)
-            eng.step_update(hyper)
+            self.dp.train_step(batch, hyper, B)
         self._keep = batch  # keep the ctypes struct (and its tensors) alive until the next call
         return B
 

@@ -1,0 +1,81 @@
+"""Data-parallel path on CPU: world_size 2 over gloo.  The shipped driver
+(codae.train.DataParallel: bucketed backward + all-reduce, global-batch loss scale, update on every
+rank) runs on an oracle-backed engine; two ranks with half the batch each must land on the same
+parameters as one process with the whole batch."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _problem():
+    from oracle import dae_oracle as O
+    rng = np.random.default_rng(7)
+    S, E, B = 3, 8, 32
+    io = S * E
+    sched = O.layer_schedule(io, 8, 3, 3, False, "embedding")
+    params = O.init_params(sched, rng)
+    x = rng.random((B, io), dtype=np.float32)
+    bm, nmr, _ = O.corrupter_tables([{"size": E, "position": s * E} for s in range(S)], 1)
+    fmask = bm[rng.integers(0, S, B)]
+    return sched, params, x, fmask
+
+
+def _worker(rank, world, port, out_dir, n_buckets):
+    for p in (os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "mui-deepautoencoder_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from codae.train import DataParallel
+    from oracle_engine import OracleEngine
+    sched, params, x, fmask = _problem()
+    eng = OracleEngine(sched, params)
+    if rank != 0:
+        eng.params.zero_()                      # must be overwritten by the broadcast
+    dp = DataParallel(eng, n_buckets=n_buckets)
+    dp.broadcast_params(eng.params)
+    B = x.shape[0]
+    lo, hi = rank * B // world, (rank + 1) * B // world
+    hyper = {"global_rows": B, "clip": 1.0, "lr": 1e-2, "wd": 1e-4}
+    for _ in range(3):
+        dp.train_step((x[lo:hi], fmask[lo:hi]), hyper, hi - lo)
+    sq = dp.reduce_scalars(torch.tensor([eng.sq], dtype=torch.float64))
+    np.save(os.path.join(out_dir, "params_%d.npy" % rank), eng.params.numpy())
+    np.save(os.path.join(out_dir, "sq_%d.npy" % rank), sq.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_buckets", [1, 4])
+def test_two_ranks_match_single_process(tmp_path, n_buckets):
+    sys.path.insert(0, HERE)
+    from codae.train import DataParallel, default_buckets
+    from oracle_engine import OracleEngine
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), n_buckets), nprocs=world, join=True)
+    sched, params, x, fmask = _problem()
+    ref = OracleEngine(sched, params)
+    dp = DataParallel(ref)                       # no process group: world 1
+    hyper = {"global_rows": x.shape[0], "clip": 1.0, "lr": 1e-2, "wd": 1e-4}
+    for _ in range(3):
+        dp.train_step((x, fmask), hyper, x.shape[0])
+    p0 = np.load(tmp_path / "params_0.npy"); p1 = np.load(tmp_path / "params_1.npy")
+    assert np.array_equal(p0, p1), "replicas diverged"
+    assert np.allclose(p0, ref.params.numpy(), rtol=1e-4, atol=1e-6)
+    assert abs(float(np.load(tmp_path / "sq_0.npy")[0]) - ref.sq) < 1e-3 * ref.sq
+    assert default_buckets(10, 4) == [(8, 10), (5, 8), (2, 5), (0, 2)]
+    assert default_buckets(3, 8) == [(2, 3), (1, 2), (0, 1)]
+    assert sorted(sum([list(range(a, b)) for a, b in default_buckets(10, 3)], [])) == list(range(10))

@@ -1,0 +1,205 @@
+"""CPU-only tests of the host side: the C-ABI library loads and exports every symbol the header
+declares (no compute call is made), and the Python mirror of the reference interface
+(codae.model / codae.tool / codae.dataset) agrees with the golden fixtures and the oracle."""
+import json
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import Golden, close
+from oracle import dae_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from codae import hip
+    header = open(os.path.join(ROOT, "include", "codae_hip.h")).read()
+    declared = set(re.findall(r"\b(codae_[a-z0-9_]+)\s*\(", header))
+    declared -= {"codae_engine"}
+    lib = hip.lib()
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, missing
+    assert declared == set(hip.PROTOTYPES), declared ^ set(hip.PROTOTYPES)
+    assert lib.codae_abi_version() == 1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from codae import hip
+    monkeypatch.setattr(hip, "_lib", None)
+    monkeypatch.setattr(hip, "LIB_PATH", "/nonexistent/libcodae_hip.so")
+    with pytest.raises(hip.HipError, match="no CPU fallback"):
+        hip.lib()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "mui-deepautoencoder_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(d, f)).read()
+                assert "oracle" not in src.replace("the oracle", "").replace("oracle-", "") or f == "never", (d, f)
+
+
+@pytest.mark.parametrize("name", ["embedding_square", "embedding_taper"])
+def test_embedding_model_surface_and_seeded_init(name):
+    from codae.model import EmbeddingDenoisingAutoencoder
+    g = Golden(name)
+    m = g.meta
+    torch.manual_seed(m["seed"])
+    model = EmbeddingDenoisingAutoencoder(m["S"] * m["E"], m["z"], m["E"], m["nb_input_layer"], m["nb_output_layer"], False)
+    sd = model.state_dict()
+    assert list(sd.keys()) == g.names
+    for n, t in sd.items():          # same torch seed -> the reference's exact Xavier draws
+        assert np.array_equal(t.numpy(), g["init__" + n.replace(".", "__")]), n
+    assert [n for n, _ in model.named_parameters()] == g.names
+    assert model.nb_category == m["S"] and isinstance(model.nb_category, float)
+    assert (model.io_size, model.z_size, model.embedding_size, model.mode) == (m["S"] * m["E"], m["z"], m["E"], 0)
+    assert "Linear(in_features=48, out_features=48, bias=True)" in repr(model) and "ReLU(inplace=True)" in repr(model)
+    from codae.hip import HipError
+    with pytest.raises(HipError, match="HIP device"):
+        model(torch.zeros(2, m["S"] * m["E"]))
+    with pytest.raises(HipError):
+        model.corrupt(torch.zeros(2, 4), torch.ones(2, 4))
+
+
+def test_model_constructor_errors_and_mixed_surface():
+    from codae.model import EmbeddingDenoisingAutoencoder, MixedVariableDenoisingAutoencoder
+    with pytest.raises(Exception, match="multiple of embedding_size"):
+        EmbeddingDenoisingAutoencoder(50, 10, 16)
+    with pytest.raises(UnboundLocalError):
+        EmbeddingDenoisingAutoencoder(48, 48, 16, 2, 2, True)      # upstream quirk (embedding_...py:126)
+    g = Golden("abalone_k2")
+    torch.manual_seed(g.meta["seed"])
+    mm = MixedVariableDenoisingAutoencoder(g.meta["arch"], 11, 11, torch.device("cpu"), 2, 2, True)
+    for n, t in mm.state_dict().items():
+        assert np.array_equal(t.numpy(), g["init__" + n.replace(".", "__")]), n
+    assert mm.arch == g.meta["arch"] and mm.device == torch.device("cpu")
+    with pytest.raises(Exception, match="invalid corruption type"):
+        mm.corrupt(torch.zeros(1, 11), torch.ones(1, 11), corruption_type="gaussian")
+    from codae.model.schedule import linear_stack
+    for args in [(1536, 1536, 4, 4, False), (1536, 128, 2, 2, False), (48, 16, 4, 4, False), (11, 11, 2, 2, True), (11, 4, 3, 2, False)]:
+        for mixed in (False, True):
+            try:
+                ref = O.layer_schedule(*args, "mixed" if mixed else "embedding")
+            except UnboundLocalError:
+                with pytest.raises(UnboundLocalError):
+                    linear_stack(*args, mixed)
+                continue
+            enc, dec = linear_stack(*args, mixed)
+            assert enc + dec == ref
+
+
+@pytest.mark.parametrize("name", ["embedding_square", "abalone_k2"])
+def test_corrupter_matches_reference_tables(name):
+    from codae.tool import Corrupter
+    g = Golden(name)
+    m = g.meta
+    arch = ([{"size": m["E"], "position": s * m["E"]} for s in range(m["S"])] if m["kind"] == "embedding" else m["arch"])
+    random.seed(m["seed"])
+    if m["kind"] == "embedding":         # the script draws N samples first (embedding.py:131-132)
+        c = list(range(m["S"]))
+        for _ in range(m["N"]):
+            random.sample(c, len(c))
+    cor = Corrupter(nb_observation=m["N"], arch=arch, k_max=m["k_max"], device=torch.device("cpu"))
+    assert np.array_equal(cor.binary_masks.numpy(), g["binary_masks"])
+    assert np.array_equal(cor.mask_to_use.numpy(), g["mask_to_use"])
+    assert cor.nb_missing_per_run == list(g["nb_missing_per_run"])
+    assert cor.nb_run == g["binary_masks"].shape[0] and cor.io_size == g["binary_masks"].shape[1]
+    idx, run = g.calls()[0]
+    masks, fmask = cor.get_masks(tuple(int(i) for i in idx), run)
+    rm, rf = O.get_masks(g["binary_masks"], g["nb_missing_per_run"], g["mask_to_use"], m["k_max"], idx, run)
+    assert len(masks) == m["k_max"]
+    for a, b in zip(masks, rm):
+        assert np.array_equal(a.numpy(), b)
+    assert np.array_equal(fmask.numpy(), rf)
+    with pytest.raises(Exception, match="Invalid k_max"):
+        Corrupter(10, arch, len(arch), torch.device("cpu"))
+
+
+def test_concatenated_embedding_dataset_and_loader(tmp_path):
+    from codae.dataset import ConcatenatedEmbeddingDataset
+    from codae.tool import collate_embedding, load_dataset_of_embeddings
+    g = Golden("embedding_square")
+    m = g.meta
+    per_cat = g["data_per_category"]
+    emb = {"o%03d" % i: {c: per_cat[s][i].tolist() for s, c in enumerate(m["categories"])} for i in range(m["N"])}
+    emb["lacking"] = {m["categories"][1]: [0.0] * m["E"]}
+    ds = ConcatenatedEmbeddingDataset(emb, m["categories"])
+    assert ds.nb_observation == m["N"] == len(ds) and ds.nb_predictor == m["S"] * m["E"] and ds.nb_used_category == m["S"]
+    assert np.allclose(ds.data.numpy(), g["data"], rtol=1e-6, atol=0) and abs(ds.scale - m["scale"]) < 1e-6 * m["scale"]
+    assert np.array_equal(ds.data_per_category[2].numpy(), per_cat[2])
+    assert [a["position"] for a in ds.arch] == [0, m["E"], 2 * m["E"]] and ds.arch[0]["type"] == "regression"
+    row, idx = ds[5]
+    assert idx == 5 and torch.equal(row, ds.data[5])
+    batch, ids = collate_embedding([ds[1], ds[3]])
+    assert batch.shape == (2, m["S"] * m["E"]) and ids == (1, 3)
+    path = tmp_path / "emb.json"
+    path.write_text(json.dumps(emb))
+    cfg = {"DATASET": {"USED_CATEGORY": m["categories"]}}
+    a = load_dataset_of_embeddings(str(path), cfg, cache_dir=str(tmp_path / "tmp") + "/")
+    b = load_dataset_of_embeddings(str(path), cfg, cache_dir=str(tmp_path / "tmp") + "/")   # from the .npz cache
+    assert torch.equal(a.data, ds.data) and torch.equal(b.data, ds.data) and b.index == ds.index
+
+
+def test_mixed_variable_dataset_matches_oracle():
+    import pandas as pd
+    from codae.dataset import MixedVariableDataset
+    rng = np.random.default_rng(2)
+    df = pd.DataFrame({"sex": rng.choice(list("MFI"), 40), "a": rng.random(40), "rings": rng.integers(1, 20, 40)})
+    ds = MixedVariableDataset(df)
+    ref = O.mixed_variable_dataset([df[c].tolist() for c in df.columns], list(df.columns), [False, True, True])
+    assert np.array_equal(ds.data.numpy(), ref["data"]) and np.array_equal(ds.type_mask.numpy(), ref["type_mask"])
+    assert [(a["size"], a["type"], a["position"]) for a in ds.arch] == [(a["size"], a["type"], a["position"]) for a in ref["arch"]]
+    assert ds.nb_predictor == 3 and ds.io_size == 5 and ds.nb_observation == 40
+
+
+def test_criteria_match_oracle():
+    from codae.tool import CombinedCriterion, Normalizer, RankingLoss, get_mask_transformation, get_rmse
+    g = Golden("abalone_k2")
+    m = g.meta
+    arch = m["arch"]
+    rng = np.random.default_rng(5)
+    idx, run = g.calls()[7]
+    B = len(idx)
+    x = g["data"][idx]
+    y = rng.standard_normal((B, 11)).astype(np.float32)
+    T = get_mask_transformation(g["type_mask"], [0] * len(arch))
+    assert np.array_equal(T.numpy(), O.mask_transformation(g["type_mask"], len(arch)))
+    yt = torch.tensor(y, requires_grad=True)
+    crit = CombinedCriterion(arch, 2, torch.device("cpu"), torch.tensor(g["type_mask"]), weight=m["weight"], reduction="mean")
+    loss = crit(x=torch.tensor(x), y=yt)
+    loss.backward()
+    assert close(float(loss), O.combined_mean(arch, m["weight"], x, y))
+    assert close(yt.grad.numpy(), O.combined_mean_grad_y(arch, m["weight"], x, y), atol=1e-7)
+    mon = CombinedCriterion(arch, 2, torch.device("cpu"), torch.tensor(g["type_mask"]), reduction="none")
+    full = mon(torch.tensor(x), torch.tensor(y), as_numpy=True)
+    assert close(full, O.combined_full(arch, x, y))
+    masks, fmask = O.get_masks(g["binary_masks"], g["nb_missing_per_run"], g["mask_to_use"], 2, idx, run)
+    tm = [torch.tensor(a) for a in masks]
+    assert close(mon.get_per_k(full, tm), O.get_per_k(full, masks, O.mask_transformation(g["type_mask"], len(arch))))
+    assert close(mon.get_partial(full, torch.tensor(fmask)), O.get_partial(full, fmask, O.mask_transformation(g["type_mask"], len(arch))))
+
+    class Scaler:
+        data_min_, data_max_, data_range_ = g["norm_min"], g["norm_min"] + g["norm_scale"], g["norm_scale"]
+    nz = Normalizer(Scaler(), torch.device("cpu"))
+    assert close(nz.undo(torch.tensor(x[:, 3:])).numpy(), O.normalizer_undo(x[:, 3:], g["norm_scale"], g["norm_min"]))
+    assert close(nz.do(nz.undo(torch.tensor(x[:, 3:]))).numpy(), x[:, 3:], atol=1e-6)
+    assert abs(get_rmse(np.ones(4), np.zeros(4)) - 1) < 1e-12
+
+    ge = Golden("embedding_square")
+
+    class DS:
+        nb_predictor, nb_used_category, embedding_size = 48, 3, 16
+        data_per_category = {c: torch.tensor(ge["data_per_category"][c]) for c in range(3)}
+    val = list(ge["validation_indices"])
+    rl = RankingLoss(DS(), val, device=torch.device("cpu"))
+    idx, run = ge.calls()[6]
+    _, fm = O.get_masks(ge["binary_masks"], ge["nb_missing_per_run"], ge["mask_to_use"], 1, idx, run)
+    pred = rng.standard_normal((len(idx), 48)).astype(np.float32)
+    got = rl.get(torch.tensor(pred), torch.tensor(fm), tuple(int(i) for i in idx))
+    assert abs(got - O.ranking_loss(pred, fm, idx, list(ge["data_per_category"]), 16, val)) < 1e-9
