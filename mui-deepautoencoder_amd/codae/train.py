@@ -20,8 +20,30 @@ early ones; clip + Adam then run identically on every rank.
 import torch
 
 
+class SubsetEpochSampler:
+    """Batches of dataset row indices in the order
+    DataLoader(dataset, batch_size, sampler=SubsetRandomSampler(indices)) yields them
+    (script/train_dae_on_embedding.py:118-128 of the reference): one draw of the loader's base
+    seed, then torch.randperm over the subset, both from torch's default generator — so a seeded
+    run visits the same batches.  Indices come back as one int64 tensor per batch; nothing is
+    gathered on the host."""
+
+    def __init__(self, indices, batch_size):
+        self.indices = torch.as_tensor(list(indices), dtype=torch.long)
+        self.batch_size = int(batch_size)
+
+    def __len__(self):
+        return (len(self.indices) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        torch.empty((), dtype=torch.int64).random_()          # DataLoader iterator's base seed
+        order = self.indices[torch.randperm(len(self.indices))]
+        for o in range(0, len(order), self.batch_size):
+            yield order[o:o + self.batch_size]
+
+
 def default_buckets(n_layers, n_buckets=4):
-    """[(lo, hi)] layer ranges in backward order, e.g. 10 layers -> (7,10) (5,7) (2,5) (0,2)."""
+    """[(lo, hi)] layer ranges in backward order, e.g. 10 layers -> (8,10) (5,8) (2,5) (0,2)."""
     n_buckets = max(1, min(n_buckets, n_layers))
     edges = [round(n_layers * i / n_buckets) for i in range(n_buckets + 1)]
     return [(edges[i], edges[i + 1]) for i in range(n_buckets - 1, -1, -1) if edges[i] < edges[i + 1]]
@@ -41,6 +63,10 @@ class DataParallel:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.buckets = default_buckets(engine.L, n_buckets)
+        # CODAE_DP_FORCE_ALLREDUCE=1: issue the bucketed collectives even with one rank (lets a
+        # single-GPU box exercise the RCCL path end to end)
+        import os
+        self.always_reduce = dist.is_initialized() and os.environ.get("CODAE_DP_FORCE_ALLREDUCE") == "1"
 
     def _weight_span(self, lo, hi):
         # weights of consecutive layers are contiguous in the flat vector
@@ -49,7 +75,7 @@ class DataParallel:
 
     def backward_and_reduce(self, B):
         eng = self.engine
-        if self.world == 1:
+        if self.world == 1 and not self.always_reduce:
             eng.step_backward(B, 0, eng.L)
             return
         works = []
@@ -122,15 +148,17 @@ class HipEmbeddingTrainer:
             return self.engine.make_batch(self.data, row_idx, None, self.mask_table, mask_to_use=self.mask_to_use, run=run)
         return self.engine.make_batch(self.data, row_idx, None, None)
 
-    def train_batch(self, row_idx, run=0, mask_id=None):
-        """One optimizer step on rows `row_idx` (int32 device tensor) of the resident dataset."""
+    def train_batch(self, row_idx, run=0, mask_id=None, global_rows=None):
+        """One optimizer step on rows `row_idx` (int32 device tensor) of the resident dataset.
+        global_rows: rows of the whole minibatch over all ranks (default: B * world)."""
         eng = self.engine
         if mask_id is None:
             batch = self._batch(row_idx, run)
         else:
             batch = eng.make_batch(self.data, row_idx, mask_id, self.mask_table)
         B = batch.B
-        hyper = eng.hyper(self.lr, self.weight_decay, self.clip, global_rows=B * self.world)
+        hyper = eng.hyper(self.lr, self.weight_decay, self.clip,
+                          global_rows=B * self.world if global_rows is None else global_rows)
         if self.dp is None:
             eng.train_step(batch, hyper)
         else:
@@ -146,10 +174,11 @@ class HipEmbeddingTrainer:
         self._keep = batch
         return y
 
-    def epoch_sums(self, reset=True):
-        """(sum (x-y)^2, sum (1-fmask)(x-y)^2) accumulated since the last reset, over all ranks."""
+    def epoch_sums(self, reset=True, reduce=True):
+        """(sum (x-y)^2, sum (1-fmask)(x-y)^2) accumulated since the last reset (summed over the
+        ranks when `reduce`)."""
         s = self.engine.scalars[:2].clone()
-        if self.dp:
+        if self.dp and reduce:
             self.dp.reduce_scalars(s)
         if reset:
             self.engine.zero_metric_sums()

@@ -269,3 +269,38 @@ def test_engine_rejects_bad_shapes():
         eng.forward(torch.zeros(65, 11, device=DEV))                         # batch > max_batch
     with pytest.raises(HipError):
         eng.forward(torch.zeros(4, 12, device=DEV))                          # wrong width
+
+
+def test_bucketed_allreduce_path_on_rccl_single_rank(monkeypatch):
+    """One-rank RCCL group with the collectives forced on: the bucketed backward + all-reduce +
+    update path must give exactly the plain fused step (sum over one rank is the identity)."""
+    import torch.distributed as dist
+    from codae.train import HipEmbeddingTrainer
+    from oracle import dae_oracle as O
+    monkeypatch.setenv("CODAE_DP_FORCE_ALLREDUCE", "1")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        S, E, B = 3, 64, 256
+        io = S * E
+        rng = np.random.default_rng(9)
+        data = rng.random((2 * B, io), dtype=np.float32)
+        sched = O.layer_schedule(io, io, 4, 4, False, "embedding")
+        params = O.init_params(sched, rng)
+        bm, _, _ = O.corrupter_tables([{"size": E, "position": s * E} for s in range(S)], 1)
+        mtu = rng.integers(0, S, (2 * B, 1)).astype(np.int32)
+        outs = []
+        for distributed in (False, True):
+            tr = HipEmbeddingTrainer(sched, torch.tensor(data), torch.tensor(bm).to(torch.uint8), torch.tensor(mtu), 1e-3, 1e-4,
+                                     1.0, max_batch=B, precision="bf16", device=DEV, distributed=distributed, n_buckets=4)
+            tr.load_params(params)
+            for s in range(3):
+                tr.train_batch(torch.arange(s * 64, s * 64 + B, dtype=torch.int32, device=DEV), run=0)
+            outs.append(tr.engine.params.clone())
+            if distributed:
+                assert tr.dp.always_reduce and len(tr.dp.buckets) == 4
+        # bias gradients are accumulated with float atomics (order varies run to run): compare to 1e-6
+        assert torch.allclose(outs[0], outs[1], rtol=0, atol=1e-6)
+    finally:
+        dist.destroy_process_group()

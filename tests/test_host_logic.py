@@ -203,3 +203,24 @@ def test_criteria_match_oracle():
     pred = rng.standard_normal((len(idx), 48)).astype(np.float32)
     got = rl.get(torch.tensor(pred), torch.tensor(fm), tuple(int(i) for i in idx))
     assert abs(got - O.ranking_loss(pred, fm, idx, list(ge["data_per_category"]), 16, val)) < 1e-9
+
+
+def test_epoch_sampler_matches_torch_dataloader_order():
+    """SubsetEpochSampler must visit the batches DataLoader(SubsetRandomSampler) would
+    (script/train_dae_on_embedding.py:118-128 of the reference), seed for seed."""
+    from torch.utils.data import DataLoader
+    from torch.utils.data.sampler import SubsetRandomSampler
+    from codae.tool import collate_embedding
+    from codae.train import SubsetEpochSampler
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self): return 100
+        def __getitem__(self, i): return torch.tensor([float(i)]), i
+    subset = [int(v) for v in np.random.default_rng(0).permutation(100)[:70]]
+    torch.manual_seed(11)
+    loader = DataLoader(DS(), batch_size=16, collate_fn=collate_embedding, sampler=SubsetRandomSampler(subset))
+    ref = [list(ids) for _ in range(2) for _, ids in loader]
+    torch.manual_seed(11)
+    mine = SubsetEpochSampler(subset, 16)
+    got = [b.tolist() for _ in range(2) for b in mine]
+    assert got == ref and len(mine) == 5
