@@ -43,6 +43,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 // round-to-nearest-even through the hardware convert (keeps NaN a NaN)
@@ -82,9 +84,11 @@ struct GemmBf16 {
     const bf16_t* relu_src; int64_t ld_relu;
     float* colsum;
     int split_k;             // >1: fp32 partial slabs C + z*M*ldc, K range split evenly in BK units
+    int dbg;                 // timing-only ablations (CODAE_GEMM_DBG): 1 no LDS-DMA, 2 no MFMA, 4 no epilogue stores
 };
 bool gemm_bf16_supported(int M, int N, int K);
 int gemm_bf16(const GemmBf16& g, hipStream_t s);
+int gemm_bf16_pipe(const GemmBf16& g, int cfg, hipStream_t s);   // gemm_bf16_pipe.hip
 
 // ---- elementwise / reductions (elementwise.hip) ----------------------------
 int launch_gather_corrupt(const codae_batch* b, void* out, int out_bf16, hipStream_t s);

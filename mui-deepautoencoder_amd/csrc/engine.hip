@@ -67,6 +67,9 @@ struct ProfScope {
     }
 };
 
+// Split-K factor of the weight-gradient GEMM dW[N][K] = dA^T H over `rows` batch rows: enough
+// K-slices that the output tiles cover the chip once (256 x 192 tiles), or ~2 workgroups per CU
+// with the 128 x 128 tile when the big one cannot fill it.  Must agree with gemm_bf16_tile_big.
 int choose_split_k(int N, int K, int rows) {
     const char* env = getenv("CODAE_WGRAD_SPLITK");
     const int kt = rows / 64;
@@ -74,8 +77,14 @@ int choose_split_k(int N, int K, int rows) {
     if (env && atoi(env) > 0) {
         s = atoi(env);
     } else {
+        const int tiles_big = ((N + 255) / 256) * ((K + 191) / 192);
+        s = (256 + tiles_big / 2) / tiles_big;
+        if (s > 8) s = 8;
+        if (s > kt) s = kt;
+        if (s < 1) s = 1;
+        if (tiles_big * s >= 160) return s;
         const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-        s = (512 + tiles / 2) / tiles;   // aim at ~2 workgroups per CU
+        s = (512 + tiles / 2) / tiles;
         if (s > 8) s = 8;
     }
     if (s > kt) s = kt;

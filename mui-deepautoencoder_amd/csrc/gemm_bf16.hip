@@ -11,14 +11,15 @@
 //
 // so no transposed copy of the weights or activations is ever written to HBM.
 //
-// Workgroup: 256 threads = 4 waves (2 x 2), tile 128 x 128 x 64, each wave 64 x 64 = 4 x 4 MFMA
-// tiles.  Both operand tiles are staged HBM -> LDS with global_load_lds_dwordx4 (LDS-DMA, 1 KiB
-// per wave-instruction, no VGPR round trip), double-buffered (64 KiB LDS, 2 workgroups per CU);
-// the LDS image is lane-linear, so the bank swizzle is applied to the per-lane SOURCE address and
-// again on the read:
-//   KC image: [128 rows][8 x 16 B chunks], chunk' = chunk ^ ((row >> 1) & 7)   -> ds_read_b128 conflict-free
-//   KS image: [64 k-rows][8 x 32 B blocks], block' = block ^ key(k-row),
-//             key = (kr & 3) | (((kr >> 3) & 1) << 2)                         -> ds_read_b64_tr_b16 conflict-free
+// Workgroup tile BM x BN x 64 with WM x WN waves: 256 x 192 with 8 waves (4 x 2, 64 x 96 per wave,
+// 112 KiB LDS, one workgroup per CU: 8192 x 1536 outputs = 32 x 8 = 256 tiles = one per CU) when
+// the problem fills the chip, else 128 x 128 with 4 waves (64 KiB LDS, two workgroups per CU).
+// Both operand tiles are staged HBM -> LDS with global_load_lds_dwordx4 (LDS-DMA, 1 KiB per
+// wave-instruction, no VGPR round trip), double-buffered; the LDS image is lane-linear, so the
+// bank swizzle is applied to the per-lane SOURCE address and again on the read:
+//   KC image: [rows][8 x 16 B chunks], chunk' = chunk ^ ((row >> 1) & 7)       -> ds_read_b128 conflict-free
+//   KS image: [64 k-rows][R/16 x 32 B blocks], block' = swizzle(block, k-row)  -> ds_read_b64_tr_b16 conflict-free
+//             (XOR for 128/256-wide tiles, rotation mod 12 for the 192-wide one; see ks_to_lds_block)
 // A k-strided operand is read with ds_read_b64_tr_b16 (hardware 4 x 16 transpose), two reads per
 // 8-element MFMA fragment, natural k order, so KC and KS operands mix freely in one MFMA.
 //
@@ -30,10 +31,7 @@
 namespace codae {
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64, NT = 256;
-constexpr int TILE_BYTES = 128 * 64 * 2;      // one operand tile (either mode) = 16 KiB
-constexpr int BUF_BYTES = 2 * TILE_BYTES;     // A + B
-constexpr int SMEM_BYTES = 2 * BUF_BYTES;     // double buffer
+constexpr int BK = 64;
 
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(1))) const void gvoid;
@@ -42,41 +40,65 @@ __device__ __forceinline__ void glds16(const void* gsrc, lds_char* dst_wave_base
     __builtin_amdgcn_global_load_lds((gvoid*)gsrc, (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
 }
 
-// Stage one operand tile.  P: operand base, ld: leading dimension (elements),
-// r0: first row (KC) / first column (KS) of the tile, rmax: number of valid rows/cols,
-// k0: first k of the tile.  Out-of-range rows / columns are clamped to valid memory
-// (their products land in output elements that are never stored).
-template <int MODE>
+// ---- k-strided (KS) image: [64 k-rows][R columns] bf16, row = 2R bytes = R/16 blocks of 32 B ----
+// A 32-lane half of one ds_read_b64_tr_b16 touches 8 k-rows (kr = 8g + q [+4], g&1 in {0,1},
+// q in 0..3) x one 32-B block; the 8 reads must fall on 8 different 32-B slots of the 256-B bank row.
+//   R = 128 / 256 (row = 1 or 2 bank rows): block' = block ^ key,  key = q | ((g & 1) << 2)
+//   R = 192 (row = 1.5 bank rows, 12 blocks): slot = (4 kr + block') mod 8, so rotate:
+//            block' = (block + rot) mod 12, rot = ((kr >> 1) & 1) + 2 ((kr >> 3) & 1)
+template <int R>
+__device__ __forceinline__ int ks_to_lds_block(int block, int kr) {
+    if constexpr (R == 192) {
+        const int b = block + ((kr >> 1) & 1) + 2 * ((kr >> 3) & 1);
+        return b >= 12 ? b - 12 : b;
+    } else {
+        return block ^ ((kr & 3) | (((kr >> 3) & 1) << 2));
+    }
+}
+template <int R>
+__device__ __forceinline__ int ks_from_lds_block(int lds_block, int kr) {
+    if constexpr (R == 192) {
+        const int b = lds_block - ((kr >> 1) & 1) - 2 * ((kr >> 3) & 1);
+        return b < 0 ? b + 12 : b;
+    } else {
+        return lds_block ^ ((kr & 3) | (((kr >> 3) & 1) << 2));
+    }
+}
+
+// Stage one operand tile of R rows (KC) / R columns (KS) x 64 k with NW waves.
+// P: operand base, ld: leading dimension (elements), r0: first row / column of the tile,
+// rmax: number of valid rows / columns, k0: first k.  Out-of-range rows / columns are clamped to
+// valid memory (their products land in output elements that are never stored).
+template <int MODE, int R, int NW>
 __device__ __forceinline__ void stage_tile(lds_char* tile, const bf16_t* __restrict__ P, int64_t ld, int r0,
                                            int rmax, int k0, int w, int lane) {
-    if constexpr (MODE == OP_KC) {
-        const int r8 = lane >> 3, cp = lane & 7;
+    constexpr int NINSTR = R * 128 / 1024;        // 1 KiB per wave-instruction
+    static_assert(NINSTR % NW == 0, "tile must split evenly over the waves");
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int rb = it * 4 + w;               // block of 8 rows
-            const int row = rb * 8 + r8;
-            const int c = cp ^ ((row >> 1) & 7);
+    for (int it = 0; it < NINSTR / NW; ++it) {
+        const int i = it * NW + w;
+        if constexpr (MODE == OP_KC) {
+            // image [R rows][8 chunks of 16 B], chunk' = chunk ^ ((row >> 1) & 7)
+            const int row = i * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
             int grow = r0 + row;
             grow = grow < rmax ? grow : rmax - 1;
-            glds16(P + (int64_t)grow * ld + k0 + c * 8, tile + rb * 1024);
-        }
-    } else {
-        const int kr4 = lane >> 4, cp = lane & 15;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int kb = it * 4 + w;               // block of 4 k-rows
-            const int kr = kb * 4 + kr4;
-            const int key = (kr & 3) | (((kr >> 3) & 1) << 2);
-            const int c = cp ^ (key << 1);
+            glds16(P + (int64_t)grow * ld + k0 + c * 8, tile + i * 1024);
+        } else {
+            constexpr int CPR = R / 8;            // 16-B chunks per k-row
+            const int q = i * 64 + lane;
+            const int kr = q / CPR;
+            const int cp = q - kr * CPR;
+            const int c = ks_from_lds_block<R>(cp >> 1, kr) * 2 + (cp & 1);
             int col = r0 + c * 8;
             col = col + 8 <= rmax ? col : rmax - 8;
-            glds16(P + (int64_t)(k0 + kr) * ld + col, tile + kb * 1024);
+            glds16(P + (int64_t)(k0 + kr) * ld + col, tile + i * 1024);
         }
     }
 }
 
 // One 8-element MFMA fragment of 16-row/col tile `t`, k-step `s` (32 deep) of an operand tile.
-template <int MODE>
+template <int MODE, int R>
 __device__ __forceinline__ bf16x8 read_frag(const lds_char* tile, int t, int s, int lane) {
     if constexpr (MODE == OP_KC) {
         const int r = lane & 15, g = lane >> 4;
@@ -85,26 +107,30 @@ __device__ __forceinline__ bf16x8 read_frag(const lds_char* tile, int t, int s, 
         return __builtin_bit_cast(bf16x8, v);
     } else {
         const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-        const int key = q | ((g & 1) << 2);
         const int kr = 32 * s + 8 * g + q;
-        const int off = kr * 256 + ((t ^ key) << 5) + 8 * p;
+        const int off = kr * (2 * R) + (ks_to_lds_block<R>(t, kr) << 5) + 8 * p;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (__attribute__((address_space(3))) s16x4*)(tile + off));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(tile + off + 4 * 256));
+            (__attribute__((address_space(3))) s16x4*)(tile + off + 4 * 2 * R));
         const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         return __builtin_bit_cast(bf16x8, v);
     }
 }
 
-template <int A_MODE, int B_MODE, bool C_F32>
-__global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
-    __shared__ __attribute__((aligned(16))) char smem_raw[SMEM_BYTES];
+// Tile BM x BN x 64, WM x WN waves, each wave (BM/WM) x (BN/WN) = TM x TN MFMA tiles of 16 x 16.
+template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, bool C_F32>
+__global__ __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256 * ((2 * (BM + BN) * 128 <= 80 * 1024) ? 2 : 1))
+void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem_raw[2 * BUF_BYTES];
     lds_char* smem = (lds_char*)smem_raw;
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wr = w >> 1, wc = w & 1;
+    const int wr = w / WN, wc = w % WN;
 
     // XCD-aware remap: consecutive tile ids (same A row panel) run on one XCD's L2
     const int nwg = gridDim.x;
@@ -121,15 +147,15 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(GemmBf16 g, int tiles_
     const int kt_end = (int)((int64_t)kt_total * (z + 1) / g.split_k);
     const int nkt = kt_end - kt_begin;
 
-    f32x4 acc[4][4];
+    f32x4 acc[TM][TN];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     if (nkt > 0) {
-        stage_tile<A_MODE>(smem, g.A, g.lda, i0, g.M, kt_begin * BK, w, lane);
-        stage_tile<B_MODE>(smem + TILE_BYTES, g.B, g.ldb, j0, g.N, kt_begin * BK, w, lane);
+        stage_tile<A_MODE, BM, NW>(smem, g.A, g.lda, i0, g.M, kt_begin * BK, w, lane);
+        stage_tile<B_MODE, BN, NW>(smem + A_BYTES, g.B, g.ldb, j0, g.N, kt_begin * BK, w, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -138,20 +164,20 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(GemmBf16 g, int tiles_
         lds_char* nxt = smem + ((kt + 1) & 1) * BUF_BYTES;
         if (kt + 1 < nkt) {
             const int k0 = (kt_begin + kt + 1) * BK;
-            stage_tile<A_MODE>(nxt, g.A, g.lda, i0, g.M, k0, w, lane);
-            stage_tile<B_MODE>(nxt + TILE_BYTES, g.B, g.ldb, j0, g.N, k0, w, lane);
+            stage_tile<A_MODE, BM, NW>(nxt, g.A, g.lda, i0, g.M, k0, w, lane);
+            stage_tile<B_MODE, BN, NW>(nxt + A_BYTES, g.B, g.ldb, j0, g.N, k0, w, lane);
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 af[4], bfr[4];
+            bf16x8 af[TM], bfr[TN];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) af[t] = read_frag<A_MODE>(cur, 4 * wr + t, s, lane);
+            for (int t = 0; t < TM; ++t) af[t] = read_frag<A_MODE, BM>(cur, TM * wr + t, s, lane);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bfr[t] = read_frag<B_MODE>(cur + TILE_BYTES, 4 * wc + t, s, lane);
+            for (int t = 0; t < TN; ++t) bfr[t] = read_frag<B_MODE, BN>(cur + A_BYTES, TN * wc + t, s, lane);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+                for (int nt = 0; nt < TN; ++nt)
                     // swapped operands: D rows <-> output column (n), D cols <-> output row (m)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], af[mt], acc[mt][nt], 0, 0, 0);
         }
@@ -161,56 +187,124 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(GemmBf16 g, int tiles_
 
     // ---- epilogue: lane holds C[i][j .. j+3], i = 16*mt + (lane & 15), j = 16*nt + 4*(lane >> 4)
     const int li = lane & 15, g4 = (lane >> 4) * 4;
+    if constexpr (!C_F32) {
+        // bf16 output: 8 B per lane straight from the accumulators would write 32-B row segments
+        // (measured ~12 us per 25 MB output).  Stage the tile through the now idle LDS and write
+        // whole rows, 16 B per lane; the ReLU-mask loads and the bias-gradient column sums ride on
+        // that pass, coalesced as well.
+        constexpr int NT = 64 * NW;
+        constexpr int PITCH = BN * 2 + 16;                 // bytes; rows stay 16-B aligned
+        static_assert(BM * PITCH <= 2 * BUF_BYTES, "output tile must fit in the staging buffers");
+        // (the K loop ended with vmcnt(0) + barrier: nobody reads the operand tiles any more)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+            const int jl = (BN / WN) * wc + 16 * nt + g4;
+            const int j = j0 + jl;
+            float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g.bias != nullptr && j < g.N) bj = *reinterpret_cast<const float4*>(g.bias + j);
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                const int il = (BM / WM) * wr + 16 * mt + li;
+                float v0 = acc[mt][nt][0] + bj.x, v1 = acc[mt][nt][1] + bj.y;
+                float v2 = acc[mt][nt][2] + bj.z, v3 = acc[mt][nt][3] + bj.w;
+                if (g.relu) {
+                    v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+                }
+                u32x2 o;
+                o[0] = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
+                o[1] = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
+                *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(smem + il * PITCH + jl * 2) = o;
+            }
+        }
+        __syncthreads();
+        constexpr int CH = BN / 8;                         // 16-B chunks per output row
+        constexpr int RL = NT / CH;                        // rows written per pass
+        const int c = threadIdx.x % CH, rl = threadIdx.x / CH;
+        const int j = j0 + c * 8;
+        float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (rl < RL && j < g.N) {
+            bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
+            for (int r = rl; r < BM; r += RL) {
+                const int i = i0 + r;
+                if (i >= g.M) break;
+                const u32x4 lv = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(smem + r * PITCH + c * 16);
+                uint4 v = make_uint4(lv[0], lv[1], lv[2], lv[3]);
+                if (g.relu_src != nullptr) {
+                    const uint4 h = *reinterpret_cast<const uint4*>(g.relu_src + (int64_t)i * g.ld_relu + j);
+                    // keep where the saved activation is > 0 (sign clear, magnitude non-zero), per bf16 half
+                    auto keep = [](uint32_t val, uint32_t hh) -> uint32_t {
+                        const uint32_t lo = ((hh & 0x8000u) == 0 && (hh & 0x7fffu) != 0) ? 0x0000ffffu : 0u;
+                        const uint32_t hi = ((hh & 0x80000000u) == 0 && (hh & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
+                        return val & (lo | hi);
+                    };
+                    v.x = keep(v.x, h.x); v.y = keep(v.y, h.y); v.z = keep(v.z, h.z); v.w = keep(v.w, h.w);
+                }
+                *reinterpret_cast<uint4*>(Cb + (int64_t)i * g.ldc + j) = v;
+                if (g.colsum != nullptr) {
+                    cs[0] += bf16_to_f32((bf16_t)(v.x & 0xffff)); cs[1] += bf16_to_f32((bf16_t)(v.x >> 16));
+                    cs[2] += bf16_to_f32((bf16_t)(v.y & 0xffff)); cs[3] += bf16_to_f32((bf16_t)(v.y >> 16));
+                    cs[4] += bf16_to_f32((bf16_t)(v.z & 0xffff)); cs[5] += bf16_to_f32((bf16_t)(v.z >> 16));
+                    cs[6] += bf16_to_f32((bf16_t)(v.w & 0xffff)); cs[7] += bf16_to_f32((bf16_t)(v.w >> 16));
+                }
+            }
+        }
+        if (g.colsum != nullptr) {
+            // column sums of the stored tile: [RL][BN] partials through LDS, then one atomic per column
+            __syncthreads();
+            float* red = reinterpret_cast<float*>(smem_raw);
+            static_assert(RL * BN * 4 <= 2 * BUF_BYTES, "reduction scratch must fit");
+            if (rl < RL) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) red[rl * BN + c * 8 + k] = cs[k];
+            }
+            __syncthreads();
+            for (int col = threadIdx.x; col < BN; col += NT) {
+                float sum = 0.f;
+                for (int r = 0; r < RL; ++r) sum += red[r * BN + col];
+                if (j0 + col < g.N) atomicAdd(&g.colsum[j0 + col], sum);
+            }
+        }
+        return;
+    }
     char* Cbase = reinterpret_cast<char*>(g.C);
     if (g.split_k > 1) Cbase += (int64_t)z * g.M * g.ldc * sizeof(float);
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int j = j0 + 64 * wc + 16 * nt + g4;
+    for (int nt = 0; nt < TN; ++nt) {
+        const int j = j0 + (BN / WN) * wc + 16 * nt + g4;
         const bool jok = j < g.N;   // N is a multiple of 8 and j of 4: j < N => j + 3 < N
         float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
         if (g.bias != nullptr && jok) bj = *reinterpret_cast<const float4*>(g.bias + j);
-        float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int i = i0 + 64 * wr + 16 * mt + li;
+        for (int mt = 0; mt < TM; ++mt) {
+            const int i = i0 + (BM / WM) * wr + 16 * mt + li;
             if (i < g.M && jok) {
                 float v0 = acc[mt][nt][0] + bj.x, v1 = acc[mt][nt][1] + bj.y;
                 float v2 = acc[mt][nt][2] + bj.z, v3 = acc[mt][nt][3] + bj.w;
                 if (g.relu) {
                     v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
                 }
-                if (g.relu_src != nullptr) {
-                    const uint2 h = *reinterpret_cast<const uint2*>(g.relu_src + (int64_t)i * g.ld_relu + j);
-                    // bf16 > 0  <=>  sign clear and magnitude non-zero
-                    v0 = ((h.x & 0x8000u) == 0 && (h.x & 0x7fffu) != 0) ? v0 : 0.f;
-                    v1 = ((h.x & 0x80000000u) == 0 && (h.x & 0x7fff0000u) != 0) ? v1 : 0.f;
-                    v2 = ((h.y & 0x8000u) == 0 && (h.y & 0x7fffu) != 0) ? v2 : 0.f;
-                    v3 = ((h.y & 0x80000000u) == 0 && (h.y & 0x7fff0000u) != 0) ? v3 : 0.f;
-                }
-                if constexpr (C_F32) {
-                    *reinterpret_cast<float4*>(Cbase + ((int64_t)i * g.ldc + j) * 4) = make_float4(v0, v1, v2, v3);
-                } else {
-                    uint2 o;
-                    o.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
-                    o.y = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
-                    *reinterpret_cast<uint2*>(Cbase + ((int64_t)i * g.ldc + j) * 2) = o;
-                }
-                cs0 += v0; cs1 += v1; cs2 += v2; cs3 += v3;
-            }
-        }
-        if (g.colsum != nullptr) {
-            // reduce over the 16 rows held by lanes with equal (lane >> 4)
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                cs0 += __shfl_xor(cs0, o); cs1 += __shfl_xor(cs1, o);
-                cs2 += __shfl_xor(cs2, o); cs3 += __shfl_xor(cs3, o);
-            }
-            if (li == 0 && jok) {
-                atomicAdd(&g.colsum[j + 0], cs0); atomicAdd(&g.colsum[j + 1], cs1);
-                atomicAdd(&g.colsum[j + 2], cs2); atomicAdd(&g.colsum[j + 3], cs3);
+                *reinterpret_cast<float4*>(Cbase + ((int64_t)i * g.ldc + j) * 4) = make_float4(v0, v1, v2, v3);
             }
         }
     }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_cfg(const GemmBf16& g, hipStream_t s) {
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int kt_total = g.K / BK;
+    const int64_t nwg = (int64_t)tiles_m * tiles_n * g.split_k;
+    CODAE_REQUIRE(nwg < (1 << 30), "gemm_bf16: grid too large");
+    dim3 grid((unsigned)nwg), block(64 * WM * WN);
+#define LAUNCH(AM, BMODE, CF) \
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, AM, BMODE, CF>), grid, block, 0, s, g, tiles_n, tiles_m * tiles_n, kt_total)
+    if (g.a_mode == OP_KC && g.b_mode == OP_KC) { if (g.c_f32) LAUNCH(OP_KC, OP_KC, true); else LAUNCH(OP_KC, OP_KC, false); }
+    else if (g.a_mode == OP_KC && g.b_mode == OP_KS) { if (g.c_f32) LAUNCH(OP_KC, OP_KS, true); else LAUNCH(OP_KC, OP_KS, false); }
+    else if (g.a_mode == OP_KS && g.b_mode == OP_KS) { if (g.c_f32) LAUNCH(OP_KS, OP_KS, true); else LAUNCH(OP_KS, OP_KS, false); }
+    else { set_error("gemm_bf16: operand mode combination not built"); return CODAE_E_UNSUPPORTED; }
+#undef LAUNCH
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
 }
 
 }  // namespace
@@ -218,6 +312,19 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(GemmBf16 g, int tiles_
 bool gemm_bf16_supported(int M, int N, int K) {
     // K: whole BK tiles; N: 16-byte rows for vector epilogue / staged chunks
     return M > 0 && N >= 8 && K >= BK && (K % BK) == 0 && (N % 8) == 0;
+}
+
+// Tile choice: the 256 x 192 / 8-wave tile when it yields enough workgroups to cover the chip
+// (its operand traffic per flop is 1.7x lower than the 128 x 128 tile's, which is what bounds
+// the small tile: ~39 TB/s of L2 reads at full MFMA rate); else 128 x 128 / 4 waves.
+int gemm_bf16_tile_big(int M, int N, int split_k) {
+    const char* env = getenv("CODAE_GEMM_TILE");
+    if (env && env[0] == 's') return 0;
+    if (env && env[0] == 'b') return 1;
+    if (env && env[0] == 'p') return 2;
+    if (env && env[0] == 'q') return 3;
+    const int64_t big = (int64_t)((M + 255) / 256) * ((N + 191) / 192) * split_k;
+    return big >= 160 ? 1 : 0;
 }
 
 int gemm_bf16(const GemmBf16& g, hipStream_t s) {
@@ -230,21 +337,15 @@ int gemm_bf16(const GemmBf16& g, hipStream_t s) {
     CODAE_REQUIRE((reinterpret_cast<uintptr_t>(g.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(g.B) & 15) == 0 &&
                       (reinterpret_cast<uintptr_t>(g.C) & 15) == 0,
                   "gemm_bf16: operands must be 16-byte aligned");
-    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-    const int kt_total = g.K / BK;
-    CODAE_REQUIRE(g.split_k <= kt_total, "gemm_bf16: split_k %d > k tiles %d", g.split_k, kt_total);
-    const int64_t nwg = (int64_t)tiles_m * tiles_n * g.split_k;
-    CODAE_REQUIRE(nwg < (1 << 30), "gemm_bf16: grid too large");
-    dim3 grid((unsigned)nwg), block(NT);
-#define LAUNCH(AM, BMODE, CF) \
-    hipLaunchKernelGGL((gemm_bf16_kernel<AM, BMODE, CF>), grid, block, 0, s, g, tiles_n, tiles_m * tiles_n, kt_total)
-    if (g.a_mode == OP_KC && g.b_mode == OP_KC) { if (g.c_f32) LAUNCH(OP_KC, OP_KC, true); else LAUNCH(OP_KC, OP_KC, false); }
-    else if (g.a_mode == OP_KC && g.b_mode == OP_KS) { if (g.c_f32) LAUNCH(OP_KC, OP_KS, true); else LAUNCH(OP_KC, OP_KS, false); }
-    else if (g.a_mode == OP_KS && g.b_mode == OP_KS) { if (g.c_f32) LAUNCH(OP_KS, OP_KS, true); else LAUNCH(OP_KS, OP_KS, false); }
-    else { set_error("gemm_bf16: operand mode combination not built"); return CODAE_E_UNSUPPORTED; }
-#undef LAUNCH
-    CODAE_LAUNCH_CHECK();
-    return CODAE_OK;
+    CODAE_REQUIRE(g.split_k <= g.K / BK, "gemm_bf16: split_k %d > k tiles %d", g.split_k, g.K / BK);
+    CODAE_REQUIRE(!g.c_f32 || (g.relu_src == nullptr && g.colsum == nullptr), "gemm_bf16: ReLU mask / column sums need bf16 output");
+    if (const char* d = getenv("CODAE_GEMM_DBG")) { GemmBf16 g2 = g; g2.dbg = atoi(d); if (g2.dbg) return gemm_bf16_pipe(g2, 0, s); }
+    switch (gemm_bf16_tile_big(g.M, g.N, g.split_k)) {
+        case 2: return gemm_bf16_pipe(g, 0, s);               // 256 x 192, 4 waves, phase-pipelined
+        case 3: return gemm_bf16_pipe(g, 1, s);               // 256 x 256, 8 waves, phase-pipelined
+        case 1: return launch_cfg<256, 192, 4, 2>(g, s);      // 256 x 192, 8 waves, one barrier per K-tile
+        default: return launch_cfg<128, 128, 2, 2>(g, s);
+    }
 }
 
 }  // namespace codae

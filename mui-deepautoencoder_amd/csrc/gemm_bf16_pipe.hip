@@ -1,0 +1,438 @@
+// Phase-pipelined bf16 GEMM for the large contractions of the DAE step (same operand modes and
+// epilogue as gemm_bf16.hip; see there for the KC / KS storage modes and the swapped-MFMA
+// epilogue).  What changes is the K loop.  Every K-tile (64 deep) is cut into four HALF-TILES
+// (A0, A1: the two halves of every wave's rows; B0, B1: likewise for its columns) and four PHASES,
+// one output quadrant of each wave per phase.  Two things run ahead of the MFMAs:
+//
+//   * LDS -> register fragment reads run ONE PHASE ahead: the phase that multiplies quadrant q
+//     first issues the ds_reads of the operand half that quadrant q+1 newly needs, into a second
+//     register set, so the LDS latency is covered by this phase's 24-32 MFMAs (one wave per SIMD:
+//     nobody else would cover it);
+//   * HBM/L2 -> LDS DMA (global_load_lds) runs SEVEN PHASES ahead: a half-tile's LDS region is
+//     dead as soon as its fragments are in registers, and is re-filled in the very next phase with
+//     the same half of the tile two K-tiles later.
+//
+//      phase   MFMA          fragment read (for)     waits for      LDS-DMA issued (region just freed)
+//      P1(t)   A0 x B0       A1(t)    (P2)           A1(t)          B0(t+2)
+//      P2(t)   A1 x B0       B1(t)    (P3)           B1(t)          A1(t+2)
+//      P3(t)   A1 x B1       A0(t+1)  (P4 .. P1)     A0(t+1)        B1(t+2)
+//      P4(t)   A0 x B1       B0(t+1)  (P1, P2)       B0(t+1)        A0(t+3)
+//
+// DMA is issued in the natural order A0 B0 A1 B1 of tile 0, 1, 2, ... and retires in order, so the
+// half a phase needs is complete once at most the 6 half-tiles issued after it are outstanding:
+// one COUNTED s_waitcnt vmcnt(3a + 3b) per phase (a / b = DMA instructions per wave per A / B
+// half-tile), never a drain inside the loop; then one raw s_barrier per phase, which both
+// publishes every wave's share of the awaited half (RAW: wait -> barrier -> ds_read) and proves the
+// region about to be re-filled is no longer read (WAR: ds_read complete, lgkmcnt(0) -> barrier ->
+// DMA issue).  Both orders hold by construction, not by timing (MI355X guide: "Read a staged
+// buffer one phase AFTER the wait that retires it").  The last two K-tiles of a workgroup, where
+// fewer loads follow, use vmcnt(0).
+//
+// Configurations (4 waves = one per SIMD, the whole 512-entry register file per wave):
+//   256 x 192 (2 x 2 waves, 128 x 96 per wave, a = 4, b = 3): 8192 x 1536 outputs = 256 workgroups
+//   256 x 256 (2 x 2 waves, 128 x 128 per wave, a = b = 4)
+#include "codae_common.h"
+
+namespace codae {
+namespace {
+
+constexpr int BK = 64;
+
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(1))) const void gvoid;
+
+__device__ __forceinline__ void glds16(const void* gsrc, lds_char* dst_wave_base) {
+    __builtin_amdgcn_global_load_lds((gvoid*)gsrc, (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// every LDS read of this wave has returned; then the workgroup barrier
+__device__ __forceinline__ void phase_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// Tell the scheduler to spread a phase's LDS reads and LDS-DMA issues between its MFMAs instead of
+// clumping them in front: at one wave per SIMD nothing else would overlap their issue cost.
+template <int N_MFMA, int N_DS, int N_VMEM>
+__device__ __forceinline__ void interleave() {
+    constexpr int ITEMS = N_DS + N_VMEM;
+    constexpr int PER = (N_MFMA / ITEMS) > 0 ? (N_MFMA / ITEMS) : 1;
+#pragma unroll
+    for (int i = 0; i < N_DS; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
+    }
+#pragma unroll
+    for (int i = 0; i < N_VMEM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);     // VMEM (LDS-DMA)
+    }
+    constexpr int REST = N_MFMA - PER * ITEMS;
+    if constexpr (REST > 0) __builtin_amdgcn_sched_group_barrier(0x008, REST, 0);
+}
+
+// ---- half-tile images ------------------------------------------------------------------------
+// A half-tile holds, for every wave row (or column) of extent S, the h-th half (S/2) of it, packed:
+// local index l in [0, RH) <-> tile index (l / (S/2)) * S + h * (S/2) + l % (S/2).
+template <int S>
+__device__ __forceinline__ int half_to_tile(int l, int h) {
+    constexpr int H = S / 2;
+    return (l / H) * S + h * H + (l % H);
+}
+
+// KS image of a half: [64 k-rows][RH columns], 32-B blocks swizzled per k-row so that the 8 rows
+// one 32-lane half of ds_read_b64_tr_b16 touches fall on 8 different 32-B slots:
+//   RH = 128 (256-B rows): block' = block ^ ((kr & 3) | (((kr >> 3) & 1) << 2))
+//   RH =  96 (192-B rows, slot = (6 kr + block') mod 8): block' = (block + ((kr >> 3) & 1)) mod 6
+template <int RH>
+__device__ __forceinline__ int ks_to_lds_block(int block, int kr) {
+    if constexpr (RH == 96) {
+        const int b = block + ((kr >> 3) & 1);
+        return b >= 6 ? b - 6 : b;
+    } else {
+        static_assert(RH == 128, "KS half image: 96 or 128 columns");
+        return block ^ ((kr & 3) | (((kr >> 3) & 1) << 2));
+    }
+}
+template <int RH>
+__device__ __forceinline__ int ks_from_lds_block(int lds_block, int kr) {
+    if constexpr (RH == 96) {
+        const int b = lds_block - ((kr >> 3) & 1);
+        return b < 0 ? b + 6 : b;
+    } else {
+        return lds_block ^ ((kr & 3) | (((kr >> 3) & 1) << 2));
+    }
+}
+
+// LDS-DMA one half-tile (RH rows/cols x 64 k = RH/8 wave-instructions, RH/8/NW per wave).
+template <int MODE, int RH, int S, int NW>
+__device__ __forceinline__ void stage_half(lds_char* img, const bf16_t* __restrict__ P, int64_t ld, int r0, int rmax,
+                                           int k0, int h, int w, int lane) {
+    constexpr int NI = RH / 8 / NW;
+    static_assert(NI * NW * 8 == RH, "half-tile must split evenly over the waves");
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int j = it * NW + w;
+        if constexpr (MODE == OP_KC) {
+            const int lr = j * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((lr >> 1) & 7);
+            int grow = r0 + half_to_tile<S>(lr, h);
+            grow = grow < rmax ? grow : rmax - 1;
+            glds16(P + (int64_t)grow * ld + k0 + c * 8, img + j * 1024);
+        } else {
+            constexpr int CPR = RH / 8;
+            const int q = j * 64 + lane;
+            const int kr = q / CPR;
+            const int cp = q - kr * CPR;
+            const int lc = (ks_from_lds_block<RH>(cp >> 1, kr) * 2 + (cp & 1)) * 8;
+            int col = r0 + half_to_tile<S>(lc, h);
+            col = col + 8 <= rmax ? col : rmax - 8;
+            glds16(P + (int64_t)(k0 + kr) * ld + col, img + j * 1024);
+        }
+    }
+}
+
+// 8-element MFMA fragment: 16-wide tile `t` (local to the half image), k-step `s`.
+template <int MODE, int RH>
+__device__ __forceinline__ bf16x8 read_frag(const lds_char* img, int t, int s, int lane) {
+    if constexpr (MODE == OP_KC) {
+        const int r = lane & 15, g = lane >> 4;
+        const int off = (16 * t + r) * 128 + (((4 * s + g) ^ (r >> 1)) << 4);
+        const s16x8 v = *reinterpret_cast<const __attribute__((address_space(3))) s16x8*>(img + off);
+        return __builtin_bit_cast(bf16x8, v);
+    } else {
+        const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+        const int kr = 32 * s + 8 * g + q;
+        const int off = kr * (2 * RH) + (ks_to_lds_block<RH>(t, kr) << 5) + 8 * p;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(img + off));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(img + off + 4 * 2 * RH));
+        const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, bool C_F32, int DBG = 0>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4)
+void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
+    constexpr int NW = WM * WN;
+    constexpr int SM = BM / WM, SN = BN / WN;        // wave sub-tile
+    constexpr int AHR = BM / 2, BHR = BN / 2;        // rows / cols per half-tile
+    constexpr int TMH = SM / 32, TNH = SN / 32;      // 16-wide MFMA tiles per wave half
+    constexpr int AH = AHR * 128, BH = BHR * 128;    // bytes per half image
+    constexpr int BUF = 2 * AH + 2 * BH;
+    constexpr int NA = AHR / 8 / NW, NB = BHR / 8 / NW;   // LDS-DMA instructions per wave per half-tile
+    static_assert(SM % 32 == 0 && SN % 32 == 0, "wave sub-tile must split into 16-wide half tiles");
+    __shared__ __attribute__((aligned(16))) char smem_raw[2 * BUF];
+    lds_char* smem = (lds_char*)smem_raw;
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = w / WN, wc = w % WN;
+
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int z = bid / tiles_mn;
+    const int tmn = bid - z * tiles_mn;
+    const int tm = tmn / tiles_n, tn = tmn - tm * tiles_n;
+    const int i0 = tm * BM, j0 = tn * BN;
+    const int kt_begin = (int)((int64_t)kt_total * z / g.split_k);
+    const int kt_end = (int)((int64_t)kt_total * (z + 1) / g.split_k);
+    const int nkt = kt_end - kt_begin;
+
+    auto a_img = [&](int tile, int h) { return smem + (tile & 1) * BUF + h * AH; };
+    auto b_img = [&](int tile, int h) { return smem + (tile & 1) * BUF + 2 * AH + h * BH; };
+    // timing-only ablations (compile-time; DBG = 0 in the shipped instantiations)
+    constexpr bool dbg_noload = DBG & 1, dbg_nomma = DBG & 2, dbg_nostore = DBG & 4;
+    // Loads past the last K-tile are issued anyway, re-reading the last tile into the (dead) region
+    // the schedule assigns: every phase stays one straight-line block the scheduler can interleave,
+    // and the vmcnt arithmetic is exact to the end (cost: ~2 extra K-tiles of L2-hit DMA per workgroup).
+    auto issue_a = [&](int tile, int h) {
+        if constexpr (!dbg_noload) {
+            const int src = tile < nkt ? tile : nkt - 1;
+            stage_half<A_MODE, AHR, SM, NW>(a_img(tile, h), g.A, g.lda, i0, g.M, (kt_begin + src) * BK, h, w, lane);
+        }
+    };
+    auto issue_b = [&](int tile, int h) {
+        if constexpr (!dbg_noload) {
+            const int src = tile < nkt ? tile : nkt - 1;
+            stage_half<B_MODE, BHR, SN, NW>(b_img(tile, h), g.B, g.ldb, j0, g.N, (kt_begin + src) * BK, h, w, lane);
+        }
+    };
+
+    f32x4 acc[2][TMH][2][TNH];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < TMH; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int d = 0; d < TNH; ++d) acc[a][b][c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 a0x[TMH][2], a0y[TMH][2], a1[TMH][2], b0[TNH][2], b1[TNH][2];
+
+    auto read_a = [&](bf16x8 (&dst)[TMH][2], int tile, int h) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int mt = 0; mt < TMH; ++mt) dst[mt][s] = read_frag<A_MODE, AHR>(a_img(tile, h), wr * TMH + mt, s, lane);
+    };
+    auto read_b = [&](bf16x8 (&dst)[TNH][2], int tile, int h) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int nt = 0; nt < TNH; ++nt) dst[nt][s] = read_frag<B_MODE, BHR>(b_img(tile, h), wc * TNH + nt, s, lane);
+    };
+    auto mma = [&](const bf16x8 (&a)[TMH][2], const bf16x8 (&b)[TNH][2], int mh, int nh) {
+        if constexpr (dbg_nomma) {
+            // keep the fragments alive so the ds_reads stay
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int mt = 0; mt < TMH; ++mt) asm volatile("" ::"v"(a[mt][s]));
+#pragma unroll
+                for (int nt = 0; nt < TNH; ++nt) asm volatile("" ::"v"(b[nt][s]));
+            }
+            return;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int mt = 0; mt < TMH; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < TNH; ++nt)
+                    acc[mh][mt][nh][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nt][s], a[mt][s], acc[mh][mt][nh][nt], 0, 0, 0);
+    };
+    // the half this phase reads has landed once at most the 6 half-tiles issued after it are in flight
+    auto wait_half = [&]() { wait_vmcnt<3 * NA + 3 * NB>(); };
+
+    // prologue = phases P3(-1), P4(-1) without MFMAs
+    issue_a(0, 0); issue_b(0, 0); issue_a(0, 1); issue_b(0, 1);
+    issue_a(1, 0); issue_b(1, 0); issue_a(1, 1);
+    wait_half();
+    phase_barrier();
+    issue_b(1, 1);
+    read_a(a0x, 0, 0);
+    wait_half();
+    phase_barrier();
+    issue_a(2, 0);
+    read_b(b0, 0, 0);
+
+    constexpr int N_MMA = 2 * TMH * TNH;
+    constexpr int RD_A = 2 * TMH * (A_MODE == OP_KC ? 1 : 2), RD_B = 2 * TNH * (B_MODE == OP_KC ? 1 : 2);
+    // one K-tile; `a0` holds A0(t), `a0n` receives A0(t+1).  Reads of a tile past the end fetch the
+    // dummy re-load and are never multiplied.
+    auto ktile = [&](int t, bf16x8 (&a0)[TMH][2], bf16x8 (&a0n)[TMH][2]) {
+        // P1: A0 x B0
+        wait_half();
+        phase_barrier();
+        issue_b(t + 2, 0);
+        read_a(a1, t, 1);
+        mma(a0, b0, 0, 0);
+        interleave<N_MMA, RD_A, NB>();
+        // P2: A1 x B0
+        wait_half();
+        phase_barrier();
+        issue_a(t + 2, 1);
+        read_b(b1, t, 1);
+        mma(a1, b0, 1, 0);
+        interleave<N_MMA, RD_B, NA>();
+        // P3: A1 x B1
+        wait_half();
+        phase_barrier();
+        issue_b(t + 2, 1);
+        read_a(a0n, t + 1, 0);
+        mma(a1, b1, 1, 1);
+        interleave<N_MMA, RD_A, NB>();
+        // P4: A0 x B1
+        wait_half();
+        phase_barrier();
+        issue_a(t + 3, 0);
+        read_b(b0, t + 1, 0);
+        mma(a0, b1, 0, 1);
+        interleave<N_MMA, RD_B, NA>();
+    };
+    int t = 0;
+    for (; t + 1 < nkt; t += 2) {
+        ktile(t, a0x, a0y);
+        ktile(t + 1, a0y, a0x);
+    }
+    if (t < nkt) ktile(t, a0x, a0y);
+    wait_vmcnt<0>();        // the trailing dummy loads must not outlive the kernel's use of LDS
+
+    // ---- epilogue: lane holds C[i][j .. j+3] of each 16 x 16 tile (swapped MFMA operands)
+    const int li = lane & 15, g4 = (lane >> 4) * 4;
+    char* Cbase = reinterpret_cast<char*>(g.C);
+    if (g.split_k > 1) Cbase += (int64_t)z * g.M * g.ldc * sizeof(float);
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int nt = 0; nt < TNH; ++nt) {
+            const int j = j0 + wc * SN + nh * (SN / 2) + 16 * nt + g4;
+            const bool jok = j < g.N;
+            float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g.bias != nullptr && jok) bj = *reinterpret_cast<const float4*>(g.bias + j);
+            float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f;
+            // ReLU masks of this column group: one batch of unconditional loads (addresses clamped into
+            // the matrix) so that they are all in flight together instead of one round trip per tile
+            uint2 hm[2][TMH];
+            if (g.relu_src != nullptr) {
+                const int jc = jok ? j : 0;
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                    for (int mt = 0; mt < TMH; ++mt) {
+                        int ic = i0 + wr * SM + mh * (SM / 2) + 16 * mt + li;
+                        ic = ic < g.M ? ic : g.M - 1;
+                        hm[mh][mt] = *reinterpret_cast<const uint2*>(g.relu_src + (int64_t)ic * g.ld_relu + jc);
+                    }
+            } else {
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                    for (int mt = 0; mt < TMH; ++mt) hm[mh][mt] = make_uint2(0x3f803f80u, 0x3f803f80u);   // 1.0: keep
+            }
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                for (int mt = 0; mt < TMH; ++mt) {
+                    const int i = i0 + wr * SM + mh * (SM / 2) + 16 * mt + li;
+                    if (i < g.M && jok && !dbg_nostore) {
+                        const f32x4 a = acc[mh][mt][nh][nt];
+                        float v0 = a[0] + bj.x, v1 = a[1] + bj.y, v2 = a[2] + bj.z, v3 = a[3] + bj.w;
+                        if (g.relu) {
+                            v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+                        }
+                        const uint2 h = hm[mh][mt];
+                        // bf16 > 0  <=>  sign clear and magnitude non-zero
+                        v0 = ((h.x & 0x8000u) == 0 && (h.x & 0x7fffu) != 0) ? v0 : 0.f;
+                        v1 = ((h.x & 0x80000000u) == 0 && (h.x & 0x7fff0000u) != 0) ? v1 : 0.f;
+                        v2 = ((h.y & 0x8000u) == 0 && (h.y & 0x7fffu) != 0) ? v2 : 0.f;
+                        v3 = ((h.y & 0x80000000u) == 0 && (h.y & 0x7fff0000u) != 0) ? v3 : 0.f;
+                        if constexpr (C_F32) {
+                            *reinterpret_cast<float4*>(Cbase + ((int64_t)i * g.ldc + j) * 4) = make_float4(v0, v1, v2, v3);
+                        } else {
+                            uint2 o;
+                            o.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
+                            o.y = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
+                            *reinterpret_cast<uint2*>(Cbase + ((int64_t)i * g.ldc + j) * 2) = o;
+                        }
+                        cs0 += v0; cs1 += v1; cs2 += v2; cs3 += v3;
+                    }
+                }
+            if (g.colsum != nullptr) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    cs0 += __shfl_xor(cs0, o); cs1 += __shfl_xor(cs1, o);
+                    cs2 += __shfl_xor(cs2, o); cs3 += __shfl_xor(cs3, o);
+                }
+                if (li == 0 && jok) {
+                    atomicAdd(&g.colsum[j + 0], cs0); atomicAdd(&g.colsum[j + 1], cs1);
+                    atomicAdd(&g.colsum[j + 2], cs2); atomicAdd(&g.colsum[j + 3], cs3);
+                }
+            }
+        }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_pipe(const GemmBf16& g, hipStream_t s) {
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int kt_total = g.K / BK;
+    const int64_t nwg = (int64_t)tiles_m * tiles_n * g.split_k;
+    CODAE_REQUIRE(nwg < (1 << 30), "gemm_bf16: grid too large");
+    dim3 grid((unsigned)nwg), block(64 * WM * WN);
+#define LAUNCH(AM, BMODE, CF) \
+    hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, WM, WN, AM, BMODE, CF>), grid, block, 0, s, g, tiles_n, tiles_m * tiles_n, kt_total)
+    if (g.a_mode == OP_KC && g.b_mode == OP_KC) { if (g.c_f32) LAUNCH(OP_KC, OP_KC, true); else LAUNCH(OP_KC, OP_KC, false); }
+    else if (g.a_mode == OP_KC && g.b_mode == OP_KS) { if (g.c_f32) LAUNCH(OP_KC, OP_KS, true); else LAUNCH(OP_KC, OP_KS, false); }
+    else if (g.a_mode == OP_KS && g.b_mode == OP_KS) { if (g.c_f32) LAUNCH(OP_KS, OP_KS, true); else LAUNCH(OP_KS, OP_KS, false); }
+    else { set_error("gemm_bf16: operand mode combination not built"); return CODAE_E_UNSUPPORTED; }
+#undef LAUNCH
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+}  // namespace
+
+// timing-only ablation builds of the forward form (KC x KC, bf16 out), 256 x 192
+template <int DBG>
+int launch_dbg(const GemmBf16& g, hipStream_t s) {
+    constexpr int BM = 256, BN = 192;
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, 2, 2, OP_KC, OP_KC, false, DBG>), dim3(tiles_m * tiles_n), dim3(256), 0, s, g,
+                       tiles_n, tiles_m * tiles_n, g.K / BK);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+// cfg 0: 256 x 192; cfg 1: 256 x 256 (both 2 x 2 waves)
+int gemm_bf16_pipe(const GemmBf16& g, int cfg, hipStream_t s) {
+    if (g.dbg && g.a_mode == OP_KC && g.b_mode == OP_KC && !g.c_f32 && g.split_k == 1) {
+        switch (g.dbg) {
+            case 1: return launch_dbg<1>(g, s);
+            case 2: return launch_dbg<2>(g, s);
+            case 3: return launch_dbg<3>(g, s);
+            case 4: return launch_dbg<4>(g, s);
+            case 5: return launch_dbg<5>(g, s);
+            case 6: return launch_dbg<6>(g, s);
+            case 7: return launch_dbg<7>(g, s);
+            default: break;
+        }
+    }
+    if (cfg == 1) return launch_pipe<256, 256, 2, 2>(g, s);
+    return launch_pipe<256, 192, 2, 2>(g, s);
+}
+
+}  // namespace codae

@@ -115,12 +115,19 @@ def ints(shape, g, lo=-3, hi=4):
     return torch.randint(lo, hi, shape, generator=g).float()
 
 
-SHAPES_BF16 = [(128, 128, 64), (64, 64, 64), (200, 192, 128), (256, 384, 384), (1000, 832, 128), (8, 64, 64)]
+SHAPES_BF16 = [(128, 128, 64), (64, 64, 64), (200, 192, 128), (256, 384, 384), (1000, 832, 128), (8, 64, 64), (520, 448, 192)]
+
+
+@pytest.fixture(params=["s", "b", "p", "q"], ids=["tile128x128", "tile256x192", "pipe256x192w4", "pipe256x256w8"])
+def tile(request, monkeypatch):
+    """force the small / big workgroup tile of the bf16 GEMM (CODAE_GEMM_TILE is read per launch)"""
+    monkeypatch.setenv("CODAE_GEMM_TILE", request.param)
+    return request.param
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES_BF16)
 @pytest.mark.parametrize("y_f32", [0, 1])
-def test_linear_bf16_exact_integers(hip, M, N, K, y_f32):
+def test_linear_bf16_exact_integers(hip, tile, M, N, K, y_f32):
     g = torch.Generator(device="cpu").manual_seed(M + 2 * N + 3 * K)
     x, W, b = ints((M, K), g), ints((N, K), g), ints((N,), g)
     xb, Wb = x.to(dev()).bfloat16(), W.to(dev()).bfloat16()
@@ -135,7 +142,7 @@ def test_linear_bf16_exact_integers(hip, M, N, K, y_f32):
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES_BF16)
-def test_dgrad_bf16_exact_integers(hip, M, N, K):
+def test_dgrad_bf16_exact_integers(hip, tile, M, N, K):
     # dx[M][K] = (dy[M][N] . W[N][K]) * [h > 0]; here the reduction dim is N (must be % 64)
     if N % 64:
         pytest.skip("reduction dim must be a multiple of 64")
@@ -153,8 +160,8 @@ def test_dgrad_bf16_exact_integers(hip, M, N, K):
     assert np.allclose(f64(db), ref.sum(0), rtol=0, atol=1e-3)
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (128, 128, 128), (512, 192, 128), (1024, 384, 384), (8192, 128, 832)])
-def test_wgrad_bf16_exact_integers(hip, M, N, K):
+@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (128, 128, 128), (512, 192, 128), (1024, 384, 384), (8192, 128, 832), (1536, 520, 200)])
+def test_wgrad_bf16_exact_integers(hip, tile, M, N, K):
     g = torch.Generator(device="cpu").manual_seed(M + N * K)
     dy, x = ints((M, N), g, -2, 3), ints((M, K), g, -2, 3)
     dyb, xb = dy.to(dev()).bfloat16(), x.to(dev()).bfloat16()
