@@ -74,6 +74,22 @@ int gemm_f32(const GemmF32& g, hipStream_t s);
 enum { OP_KC = 0,  // operand stored [rows][k] (k contiguous)
        OP_KS = 1   // operand stored [k][rows] (rows contiguous; transposed LDS reads)
 };
+// MSE loss folded into the epilogue of the last forward GEMM (train_dae_on_embedding.py:206-223):
+// the kernel then writes dL/dy (bf16) instead of y and accumulates the metric sums.
+struct LossFuse {
+    int enabled;
+    const float* data;            // dataset [n][io] fp32
+    const int32_t* row_idx;       // [rows] or null
+    const int32_t* mask_id;       // [rows] or null
+    const int32_t* mask_to_use;   // [n][nb_run] or null
+    int nb_run, run;
+    const uint8_t* table;         // [n_masks][io]
+    int io;
+    int B;                        // valid batch rows; rows in [B, M) get dy = 0
+    float inv_n;                  // 1 / (global rows * io)
+    double* scalars;
+};
+
 struct GemmBf16 {
     const bf16_t* A; int64_t lda; int a_mode;   // output row index i
     const bf16_t* B; int64_t ldb; int b_mode;   // output col index j
@@ -84,6 +100,7 @@ struct GemmBf16 {
     const bf16_t* relu_src; int64_t ld_relu;
     float* colsum;
     int split_k;             // >1: fp32 partial slabs C + z*M*ldc, K range split evenly in BK units
+    LossFuse loss;           // enabled: C receives dy (bf16), colsum the last bias gradient
     int dbg;                 // timing-only ablations (CODAE_GEMM_DBG): 1 no LDS-DMA, 2 no MFMA, 4 no epilogue stores
 };
 bool gemm_bf16_supported(int M, int N, int K);

@@ -139,7 +139,8 @@ __global__ __launch_bounds__(NT) void expand_masks_kernel(const int32_t* __restr
 //   dy = 2 (y - x) * inv_n                          (autograd of train_dae_on_embedding.py:206)
 //   SQ_FULL    += sum (x-y)^2                        (:218-220)
 //   SQ_PARTIAL += sum (1-fmask)(x-y)^2               (:223)
-constexpr int LOSS_ROWS = 32;
+constexpr int LOSS_ROWS = 32;   // rows per block: each block costs `io` column-sum atomics, so keep blocks few
+constexpr int LOSS_UNROLL = 8;  // rows in flight per thread
 template <bool VEC, bool DY_BF16>
 __global__ __launch_bounds__(NT) void mse_loss_kernel(const float* __restrict__ data,
                                                       const int32_t* __restrict__ row_idx,
@@ -154,12 +155,18 @@ __global__ __launch_bounds__(NT) void mse_loss_kernel(const float* __restrict__ 
     constexpr int W = VEC ? 4 : 1;
     const int cols = io / W;
     const int r_begin = blockIdx.x * LOSS_ROWS;
-    const int r_end = min(B, r_begin + LOSS_ROWS);
     float sq = 0.f, sqp = 0.f;
     for (int cv = threadIdx.x; cv < cols; cv += NT) {
         const int c = cv * W;
         float cs[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int b = r_begin; b < r_end; ++b) {
+        // rows are independent: unrolled with clamped (always valid) addresses so that the loads of
+        // all LOSS_ROWS rows are in flight together; rows past the batch contribute nothing
+        for (int r0 = 0; r0 < LOSS_ROWS; r0 += LOSS_UNROLL)
+#pragma unroll
+        for (int ru = 0; ru < LOSS_UNROLL; ++ru) {
+            const int rr = r0 + ru;
+            const bool live = r_begin + rr < B;
+            const int b = live ? r_begin + rr : B - 1;
             const int64_t src_row = row_idx ? row_idx[b] : b;
             float xv[4], yv[4];
             uint32_t m = 0x01010101u;
@@ -178,14 +185,14 @@ __global__ __launch_bounds__(NT) void mse_loss_kernel(const float* __restrict__ 
             float g[4];
 #pragma unroll
             for (int k = 0; k < W; ++k) {
-                const float d = xv[k] - yv[k];
+                const float d = live ? xv[k] - yv[k] : 0.f;
                 const float se = d * d;
                 sq += se;
                 if (((m >> (8 * k)) & 0xff) == 0) sqp += se;
                 g[k] = -2.f * d * inv_n;
                 cs[k] += g[k];
             }
-            if (want_grad) {
+            if (want_grad && live) {
                 const int64_t o = (int64_t)b * io + c;
                 if constexpr (DY_BF16) {
                     bf16_t* op = reinterpret_cast<bf16_t*>(dy) + o;

@@ -443,8 +443,32 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
     rc = zero_pad_rows(h, act_ptr(h, b, 0), B, rows, h->in[0], s);
     if (rc) return rc;
     float* y = out_y ? out_y : reinterpret_cast<float*>(act_ptr(h, b, L));
+    // bf16 training step: the loss is folded into the last forward GEMM's epilogue (y never stored)
+    const bool fuse_loss = bf && hyper != nullptr && out_y == nullptr && getenv("CODAE_NO_FUSED_LOSS") == nullptr;
     for (int l = 0; l < L; ++l) {
         const bool last = (l == L - 1);
+        if (last && fuse_loss) {
+            rc = zero_bias_grads(h, b, s);
+            if (rc) return rc;
+            const double n_glob = (double)(hyper->loss_scale_rows > 0.f ? hyper->loss_scale_rows : (float)B) * batch->io;
+            GemmBf16 g{};
+            g.A = reinterpret_cast<const bf16_t*>(act_ptr(h, b, l)); g.lda = h->in[l]; g.a_mode = OP_KC;
+            g.B = reinterpret_cast<const bf16_t*>(b->shadow_w) + h->w_off[l]; g.ldb = h->in[l]; g.b_mode = OP_KC;
+            g.C = dact_ptr(h, b, l); g.ldc = h->out[l]; g.c_f32 = 0;
+            g.M = rows; g.N = h->out[l]; g.K = h->in[l];
+            g.bias = b->params + h->b_off[l]; g.relu = 0; g.split_k = 1;
+            g.colsum = b->grads + h->b_off[l];
+            g.loss.enabled = 1; g.loss.data = batch->data; g.loss.row_idx = batch->row_idx; g.loss.mask_id = batch->mask_id;
+            g.loss.mask_to_use = batch->mask_to_use; g.loss.nb_run = batch->nb_run; g.loss.run = batch->run;
+            g.loss.table = batch->mask_table; g.loss.io = batch->io; g.loss.B = B; g.loss.inv_n = (float)(1.0 / n_glob);
+            g.loss.scalars = b->scalars;
+            {
+                ProfScope prof(h, CODAE_K_GEMM_FWD, s);
+                rc = gemm_bf16(g, s);
+            }
+            if (rc) return rc;
+            return launch_finish_loss(b->scalars, 1.0 / ((double)B * batch->io), s);
+        }
         rc = last ? run_linear(h, b, l, act_ptr(h, b, l), y, true, B, s)
                   : run_linear(h, b, l, act_ptr(h, b, l), act_ptr(h, b, l + 1), false, rows, s);
         if (rc) return rc;

@@ -119,7 +119,7 @@ __device__ __forceinline__ bf16x8 read_frag(const lds_char* tile, int t, int s, 
 }
 
 // Tile BM x BN x 64, WM x WN waves, each wave (BM/WM) x (BN/WN) = TM x TN MFMA tiles of 16 x 16.
-template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, bool C_F32>
+template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, bool C_F32, bool LOSS = false>
 __global__ __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256 * ((2 * (BM + BN) * 128 <= 80 * 1024) ? 2 : 1))
 void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
     constexpr int NW = WM * WN;
@@ -167,26 +167,135 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
             stage_tile<A_MODE, BM, NW>(nxt, g.A, g.lda, i0, g.M, k0, w, lane);
             stage_tile<B_MODE, BN, NW>(nxt + A_BYTES, g.B, g.ldb, j0, g.N, k0, w, lane);
         }
+        // fragments of BOTH k-steps are requested up front: the MFMAs of k-step 0 start as soon as
+        // their operands are back (counted lgkmcnt) while the reads of k-step 1 are still in flight
+        bf16x8 af[2][TM], bfr[2][TN];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 af[TM], bfr[TN];
 #pragma unroll
-            for (int t = 0; t < TM; ++t) af[t] = read_frag<A_MODE, BM>(cur, TM * wr + t, s, lane);
+            for (int t = 0; t < TM; ++t) af[s][t] = read_frag<A_MODE, BM>(cur, TM * wr + t, s, lane);
 #pragma unroll
-            for (int t = 0; t < TN; ++t) bfr[t] = read_frag<B_MODE, BN>(cur + A_BYTES, TN * wc + t, s, lane);
+            for (int t = 0; t < TN; ++t) bfr[s][t] = read_frag<B_MODE, BN>(cur + A_BYTES, TN * wc + t, s, lane);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < TN; ++nt)
                     // swapped operands: D rows <-> output column (n), D cols <-> output row (m)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], af[mt], acc[mt][nt], 0, 0, 0);
-        }
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s][nt], af[s][mt], acc[mt][nt], 0, 0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
     // ---- epilogue: lane holds C[i][j .. j+3], i = 16*mt + (lane & 15), j = 16*nt + 4*(lane >> 4)
     const int li = lane & 15, g4 = (lane >> 4) * 4;
+    if constexpr (LOSS) {
+        // Last forward layer of a training step: y = acc + bias never goes to HBM.  The fp32 tile is
+        // staged through LDS in two row halves; each pass reads x (gathered dataset rows, fp32) and
+        // the mask bytes coalesced, writes dy = 2 (y - x) / n as bf16 in whole rows, and accumulates
+        // sum (x-y)^2, sum (1-m)(x-y)^2 and the column sums of dy (= bias gradient).
+        constexpr int NT = 64 * NW;
+        constexpr int HR = BM / 2;                              // rows per pass
+        constexpr int PITCH = BN * 4 + 16;
+        static_assert(HR * PITCH <= 2 * BUF_BYTES, "fp32 half tile must fit in the staging buffers");
+        static_assert((BM / WM) <= HR, "a wave's rows must lie in one half");
+        constexpr int CH = BN / 8, RL = NT / CH;
+        const LossFuse& L = g.loss;
+        const bool masked = (L.mask_id != nullptr) || (L.mask_to_use != nullptr);
+        const int c = threadIdx.x % CH, rl = threadIdx.x / CH;
+        const int j = j0 + c * 8;
+        float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float sq = 0.f, sqp = 0.f;
+        bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            if (((BM / WM) * wr) / HR == hh) {
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt) {
+                    const int jl = (BN / WN) * wc + 16 * nt + g4;
+                    float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (g.bias != nullptr && j0 + jl < g.N) bj = *reinterpret_cast<const float4*>(g.bias + j0 + jl);
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt) {
+                        const int il = (BM / WM) * wr + 16 * mt + li - hh * HR;
+                        f32x4 v = acc[mt][nt];
+                        v[0] += bj.x; v[1] += bj.y; v[2] += bj.z; v[3] += bj.w;
+                        *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(smem + il * PITCH + jl * 4) = v;
+                    }
+                }
+            }
+            __syncthreads();
+            if (rl < RL && j < g.N) {
+                for (int r = rl; r < HR; r += RL) {
+                    const int i = i0 + hh * HR + r;
+                    if (i >= g.M) break;
+                    uint4 o = make_uint4(0u, 0u, 0u, 0u);
+                    if (i < L.B) {
+                        const int64_t src_row = L.row_idx ? L.row_idx[i] : i;
+                        const float* xp = L.data + src_row * L.io + j;
+                        const float4 xa = *reinterpret_cast<const float4*>(xp);
+                        const float4 xb = *reinterpret_cast<const float4*>(xp + 4);
+                        const f32x4 ya = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(smem + r * PITCH + c * 32);
+                        const f32x4 yb = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(smem + r * PITCH + c * 32 + 16);
+                        uint2 m = make_uint2(0x01010101u, 0x01010101u);
+                        if (masked) {
+                            const int id = L.mask_id ? L.mask_id[i] : L.mask_to_use[src_row * L.nb_run + L.run];
+                            m = *reinterpret_cast<const uint2*>(L.table + (int64_t)id * L.io + j);
+                        }
+                        const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                        const float yv[8] = {ya[0], ya[1], ya[2], ya[3], yb[0], yb[1], yb[2], yb[3]};
+                        float gq[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const float d = xv[k] - yv[k];
+                            const float se = d * d;
+                            sq += se;
+                            const uint32_t mb = ((k < 4 ? m.x : m.y) >> (8 * (k & 3))) & 0xff;
+                            if (mb == 0) sqp += se;
+                            gq[k] = -2.f * d * L.inv_n;
+                        }
+                        o.x = (uint32_t)f32_to_bf16(gq[0]) | ((uint32_t)f32_to_bf16(gq[1]) << 16);
+                        o.y = (uint32_t)f32_to_bf16(gq[2]) | ((uint32_t)f32_to_bf16(gq[3]) << 16);
+                        o.z = (uint32_t)f32_to_bf16(gq[4]) | ((uint32_t)f32_to_bf16(gq[5]) << 16);
+                        o.w = (uint32_t)f32_to_bf16(gq[6]) | ((uint32_t)f32_to_bf16(gq[7]) << 16);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) cs[k] += gq[k];
+                    }
+                    *reinterpret_cast<uint4*>(Cb + (int64_t)i * g.ldc + j) = o;
+                }
+            }
+            __syncthreads();
+        }
+        // block sums -> scalars; column sums -> bias gradient
+        float* red = reinterpret_cast<float*>(smem_raw);
+        static_assert(RL * BN * 4 + 64 <= 2 * BUF_BYTES, "reduction scratch must fit");
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) { sq += __shfl_xor(sq, o2); sqp += __shfl_xor(sqp, o2); }
+        float* wsum = red + RL * BN;
+        if (lane == 0) { wsum[2 * w] = sq; wsum[2 * w + 1] = sqp; }
+        if (rl < RL) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) red[rl * BN + c * 8 + k] = cs[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float a = 0.f, b2 = 0.f;
+            for (int ww = 0; ww < NW; ++ww) { a += wsum[2 * ww]; b2 += wsum[2 * ww + 1]; }
+            atomicAdd(&L.scalars[CODAE_S_SQ_FULL], (double)a);
+            atomicAdd(&L.scalars[CODAE_S_STEP_SQ], (double)a);
+            if (masked) atomicAdd(&L.scalars[CODAE_S_SQ_PARTIAL], (double)b2);
+        }
+        if (g.colsum != nullptr) {
+            for (int col = threadIdx.x; col < BN; col += NT) {
+                float sum = 0.f;
+                for (int r = 0; r < RL; ++r) sum += red[r * BN + col];
+                if (j0 + col < g.N) atomicAdd(&g.colsum[j0 + col], sum);
+            }
+        }
+        return;
+    }
     if constexpr (!C_F32) {
         // bf16 output: 8 B per lane straight from the accumulators would write 32-B row segments
         // (measured ~12 us per 25 MB output).  Stage the tile through the now idle LDS and write
@@ -298,7 +407,10 @@ int launch_cfg(const GemmBf16& g, hipStream_t s) {
     dim3 grid((unsigned)nwg), block(64 * WM * WN);
 #define LAUNCH(AM, BMODE, CF) \
     hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, AM, BMODE, CF>), grid, block, 0, s, g, tiles_n, tiles_m * tiles_n, kt_total)
-    if (g.a_mode == OP_KC && g.b_mode == OP_KC) { if (g.c_f32) LAUNCH(OP_KC, OP_KC, true); else LAUNCH(OP_KC, OP_KC, false); }
+    if (g.loss.enabled) {
+        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, OP_KC, OP_KC, false, true>), grid, block, 0, s, g, tiles_n,
+                           tiles_m * tiles_n, kt_total);
+    } else if (g.a_mode == OP_KC && g.b_mode == OP_KC) { if (g.c_f32) LAUNCH(OP_KC, OP_KC, true); else LAUNCH(OP_KC, OP_KC, false); }
     else if (g.a_mode == OP_KC && g.b_mode == OP_KS) { if (g.c_f32) LAUNCH(OP_KC, OP_KS, true); else LAUNCH(OP_KC, OP_KS, false); }
     else if (g.a_mode == OP_KS && g.b_mode == OP_KS) { if (g.c_f32) LAUNCH(OP_KS, OP_KS, true); else LAUNCH(OP_KS, OP_KS, false); }
     else { set_error("gemm_bf16: operand mode combination not built"); return CODAE_E_UNSUPPORTED; }
@@ -339,7 +451,20 @@ int gemm_bf16(const GemmBf16& g, hipStream_t s) {
                   "gemm_bf16: operands must be 16-byte aligned");
     CODAE_REQUIRE(g.split_k <= g.K / BK, "gemm_bf16: split_k %d > k tiles %d", g.split_k, g.K / BK);
     CODAE_REQUIRE(!g.c_f32 || (g.relu_src == nullptr && g.colsum == nullptr), "gemm_bf16: ReLU mask / column sums need bf16 output");
+    if (g.loss.enabled) {
+        CODAE_REQUIRE(g.a_mode == OP_KC && g.b_mode == OP_KC && !g.c_f32 && g.split_k == 1 && !g.relu && !g.relu_src,
+                      "gemm_bf16: fused loss only on the plain forward form");
+        CODAE_REQUIRE(g.loss.data && g.loss.scalars && g.loss.io == g.N && g.loss.B <= g.M && (g.N % 8) == 0,
+                      "gemm_bf16: fused loss arguments");
+        CODAE_REQUIRE(!(g.loss.mask_id || g.loss.mask_to_use) || ((reinterpret_cast<uintptr_t>(g.loss.table) & 7) == 0),
+                      "gemm_bf16: mask table must be 8-byte aligned");
+        CODAE_REQUIRE((reinterpret_cast<uintptr_t>(g.loss.data) & 15) == 0, "gemm_bf16: dataset must be 16-byte aligned");
+    }
     if (const char* d = getenv("CODAE_GEMM_DBG")) { GemmBf16 g2 = g; g2.dbg = atoi(d); if (g2.dbg) return gemm_bf16_pipe(g2, 0, s); }
+    if (g.loss.enabled) {
+        if (gemm_bf16_tile_big(g.M, g.N, 1)) return launch_cfg<256, 192, 4, 2>(g, s);
+        return launch_cfg<128, 128, 2, 2>(g, s);
+    }
     switch (gemm_bf16_tile_big(g.M, g.N, g.split_k)) {
         case 2: return gemm_bf16_pipe(g, 0, s);               // 256 x 192, 4 waves, phase-pipelined
         case 3: return gemm_bf16_pipe(g, 1, s);               // 256 x 256, 8 waves, phase-pipelined

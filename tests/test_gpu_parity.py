@@ -304,3 +304,39 @@ def test_bucketed_allreduce_path_on_rccl_single_rank(monkeypatch):
         assert torch.allclose(outs[0], outs[1], rtol=0, atol=1e-6)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("S,E,B", [(3, 128, 1000), (3, 320, 8192)], ids=["tile128x128", "tile256x192"])
+def test_fused_loss_epilogue_matches_separate_loss_kernel(monkeypatch, S, E, B):
+    """bf16 training step with the MSE loss folded into the last forward GEMM vs the same step with
+    the stand-alone loss kernel (CODAE_NO_FUSED_LOSS=1): same dY up to bf16 rounding of y, so loss,
+    metric sums and gradient norm must agree closely; ragged B exercises the zeroed pad rows."""
+    from codae.train import HipEmbeddingTrainer
+    from oracle import dae_oracle as O
+    io = S * E
+    rng = np.random.default_rng(11)
+    N = B + 100
+    data = rng.random((N, io), dtype=np.float32)
+    sched = O.layer_schedule(io, io, 2, 2, False, "embedding")
+    params = O.init_params(sched, rng)
+    bm, _, _ = O.corrupter_tables([{"size": E, "position": s * E} for s in range(S)], 1)
+    mtu = rng.integers(0, S, (N, 1)).astype(np.int32)
+    idx = torch.tensor(rng.permutation(N)[:B], dtype=torch.int32, device=DEV)
+    res = []
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv("CODAE_NO_FUSED_LOSS", raising=False)
+        else:
+            monkeypatch.setenv("CODAE_NO_FUSED_LOSS", "1")
+        tr = HipEmbeddingTrainer(sched, torch.tensor(data), torch.tensor(bm).to(torch.uint8), torch.tensor(mtu), 1e-3, 1e-4, 1.0,
+                                 max_batch=B, precision="bf16", device=DEV)
+        tr.load_params(params)
+        tr.train_batch(idx, run=0)
+        sq, sqp, gsq, loss = tr.engine.read_scalars()
+        res.append((sq, sqp, gsq ** 0.5, loss, tr.engine.bias_grad(tr.engine.L - 1).cpu().numpy().copy(),
+                    tr.engine.weight_grad(0).cpu().numpy().copy()))
+    a, b = res
+    for k in range(4):
+        assert abs(a[k] - b[k]) <= 2e-3 * abs(b[k]), (k, a[k], b[k])
+    assert np.allclose(a[4], b[4], rtol=2e-2, atol=1e-7)          # last-layer bias gradient
+    assert np.allclose(a[5], b[5], rtol=5e-2, atol=2e-6)          # first-layer weight gradient (through the whole chain)
