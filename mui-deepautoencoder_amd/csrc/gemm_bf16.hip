@@ -69,6 +69,29 @@ __device__ __forceinline__ int ks_from_lds_block(int lds_block, int kr) {
 // P: operand base, ld: leading dimension (elements), r0: first row / column of the tile,
 // rmax: number of valid rows / columns, k0: first k.  Out-of-range rows / columns are clamped to
 // valid memory (their products land in output elements that are never stored).
+// global source of the 16 bytes that lane `lane` of wave-instruction `i` places at tile + i*1024 + lane*16
+template <int MODE, int R>
+__device__ __forceinline__ const bf16_t* stage_src(const bf16_t* __restrict__ P, int64_t ld, int r0, int rmax, int k0,
+                                                   int i, int lane) {
+    if constexpr (MODE == OP_KC) {
+        // image [R rows][8 chunks of 16 B], chunk' = chunk ^ ((row >> 1) & 7)
+        const int row = i * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int grow = r0 + row;
+        grow = grow < rmax ? grow : rmax - 1;
+        return P + (int64_t)grow * ld + k0 + c * 8;
+    } else {
+        constexpr int CPR = R / 8;            // 16-B chunks per k-row
+        const int q = i * 64 + lane;
+        const int kr = q / CPR;
+        const int cp = q - kr * CPR;
+        const int c = ks_from_lds_block<R>(cp >> 1, kr) * 2 + (cp & 1);
+        int col = r0 + c * 8;
+        col = col + 8 <= rmax ? col : rmax - 8;
+        return P + (int64_t)(k0 + kr) * ld + col;
+    }
+}
+
 template <int MODE, int R, int NW>
 __device__ __forceinline__ void stage_tile(lds_char* tile, const bf16_t* __restrict__ P, int64_t ld, int r0,
                                            int rmax, int k0, int w, int lane) {
@@ -77,24 +100,25 @@ __device__ __forceinline__ void stage_tile(lds_char* tile, const bf16_t* __restr
 #pragma unroll
     for (int it = 0; it < NINSTR / NW; ++it) {
         const int i = it * NW + w;
-        if constexpr (MODE == OP_KC) {
-            // image [R rows][8 chunks of 16 B], chunk' = chunk ^ ((row >> 1) & 7)
-            const int row = i * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ ((row >> 1) & 7);
-            int grow = r0 + row;
-            grow = grow < rmax ? grow : rmax - 1;
-            glds16(P + (int64_t)grow * ld + k0 + c * 8, tile + i * 1024);
-        } else {
-            constexpr int CPR = R / 8;            // 16-B chunks per k-row
-            const int q = i * 64 + lane;
-            const int kr = q / CPR;
-            const int cp = q - kr * CPR;
-            const int c = ks_from_lds_block<R>(cp >> 1, kr) * 2 + (cp & 1);
-            int col = r0 + c * 8;
-            col = col + 8 <= rmax ? col : rmax - 8;
-            glds16(P + (int64_t)(k0 + kr) * ld + col, tile + i * 1024);
-        }
+        glds16(stage_src<MODE, R>(P, ld, r0, rmax, k0, i, lane), tile + i * 1024);
     }
+}
+
+// The same tile through the second load path: global_load_dwordx4 into registers now, one lane-linear
+// ds_write_b128 per instruction later (the image is identical to the LDS-DMA one).  The LDS-DMA path
+// of a CU saturates near 70-76 GB/s; splitting the two operands over both paths halves its load.
+template <int MODE, int R, int NW>
+__device__ __forceinline__ void stage_tile_load(u32x4 (&regs)[R * 128 / 1024 / NW], const bf16_t* __restrict__ P, int64_t ld,
+                                                int r0, int rmax, int k0, int w, int lane) {
+#pragma unroll
+    for (int it = 0; it < R * 128 / 1024 / NW; ++it)
+        regs[it] = *reinterpret_cast<const u32x4*>(stage_src<MODE, R>(P, ld, r0, rmax, k0, it * NW + w, lane));
+}
+template <int R, int NW>
+__device__ __forceinline__ void stage_tile_write(lds_char* tile, const u32x4 (&regs)[R * 128 / 1024 / NW], int w, int lane) {
+#pragma unroll
+    for (int it = 0; it < R * 128 / 1024 / NW; ++it)
+        *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(tile + (it * NW + w) * 1024 + lane * 16) = regs[it];
 }
 
 // One 8-element MFMA fragment of 16-row/col tile `t`, k-step `s` (32 deep) of an operand tile.
@@ -119,7 +143,7 @@ __device__ __forceinline__ bf16x8 read_frag(const lds_char* tile, int t, int s, 
 }
 
 // Tile BM x BN x 64, WM x WN waves, each wave (BM/WM) x (BN/WN) = TM x TN MFMA tiles of 16 x 16.
-template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, bool C_F32, bool LOSS = false>
+template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, bool C_F32, bool LOSS = false, bool B_REGS = false>
 __global__ __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256 * ((2 * (BM + BN) * 128 <= 80 * 1024) ? 2 : 1))
 void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
     constexpr int NW = WM * WN;
@@ -153,9 +177,15 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
 #pragma unroll
         for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    u32x4 breg[BN * 128 / 1024 / NW];
     if (nkt > 0) {
         stage_tile<A_MODE, BM, NW>(smem, g.A, g.lda, i0, g.M, kt_begin * BK, w, lane);
-        stage_tile<B_MODE, BN, NW>(smem + A_BYTES, g.B, g.ldb, j0, g.N, kt_begin * BK, w, lane);
+        if constexpr (B_REGS) {
+            stage_tile_load<B_MODE, BN, NW>(breg, g.B, g.ldb, j0, g.N, kt_begin * BK, w, lane);
+            stage_tile_write<BN, NW>(smem + A_BYTES, breg, w, lane);
+        } else {
+            stage_tile<B_MODE, BN, NW>(smem + A_BYTES, g.B, g.ldb, j0, g.N, kt_begin * BK, w, lane);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -165,7 +195,8 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
         if (kt + 1 < nkt) {
             const int k0 = (kt_begin + kt + 1) * BK;
             stage_tile<A_MODE, BM, NW>(nxt, g.A, g.lda, i0, g.M, k0, w, lane);
-            stage_tile<B_MODE, BN, NW>(nxt + A_BYTES, g.B, g.ldb, j0, g.N, k0, w, lane);
+            if constexpr (B_REGS) stage_tile_load<B_MODE, BN, NW>(breg, g.B, g.ldb, j0, g.N, k0, w, lane);
+            else stage_tile<B_MODE, BN, NW>(nxt + A_BYTES, g.B, g.ldb, j0, g.N, k0, w, lane);
         }
         // fragments of BOTH k-steps are requested up front: the MFMAs of k-step 0 start as soon as
         // their operands are back (counted lgkmcnt) while the reads of k-step 1 are still in flight
@@ -185,6 +216,10 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
                 for (int nt = 0; nt < TN; ++nt)
                     // swapped operands: D rows <-> output column (n), D cols <-> output row (m)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s][nt], af[s][mt], acc[mt][nt], 0, 0, 0);
+        if constexpr (B_REGS) {
+            // nxt's B image was last read one iteration ago (a barrier since): write it now
+            if (kt + 1 < nkt) stage_tile_write<BN, NW>(nxt + A_BYTES, breg, w, lane);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -429,14 +464,17 @@ bool gemm_bf16_supported(int M, int N, int K) {
 // Tile choice: the 256 x 192 / 8-wave tile when it yields enough workgroups to cover the chip
 // (its operand traffic per flop is 1.7x lower than the 128 x 128 tile's, which is what bounds
 // the small tile: ~39 TB/s of L2 reads at full MFMA rate); else 128 x 128 / 4 waves.
-int gemm_bf16_tile_big(int M, int N, int split_k) {
+int gemm_bf16_tile_big(int M, int N, int split_k, bool k_strided = false) {
     const char* env = getenv("CODAE_GEMM_TILE");
     if (env && env[0] == 's') return 0;
     if (env && env[0] == 'b') return 1;
     if (env && env[0] == 'p') return 2;
     if (env && env[0] == 'q') return 3;
+    if (env && env[0] == 'c') return 4;
     const int64_t big = (int64_t)((M + 255) / 256) * ((N + 191) / 192) * split_k;
-    return big >= 160 ? 1 : 0;
+    // measured (tools/bench_gemm.py, 8192 x 1536 x 1536): forward 38 us with 256x192/8 waves vs 41 with
+    // two 128x192 workgroups per CU; dgrad 51 vs 47; wgrad 60 vs 56
+    return big >= 160 ? (k_strided ? 4 : 1) : 0;
 }
 
 int gemm_bf16(const GemmBf16& g, hipStream_t s) {
@@ -462,13 +500,16 @@ int gemm_bf16(const GemmBf16& g, hipStream_t s) {
     }
     if (const char* d = getenv("CODAE_GEMM_DBG")) { GemmBf16 g2 = g; g2.dbg = atoi(d); if (g2.dbg) return gemm_bf16_pipe(g2, 0, s); }
     if (g.loss.enabled) {
-        if (gemm_bf16_tile_big(g.M, g.N, 1)) return launch_cfg<256, 192, 4, 2>(g, s);
+        const int t = gemm_bf16_tile_big(g.M, g.N, 1);
+        if (t == 4) return launch_cfg<128, 192, 2, 2>(g, s);
+        if (t) return launch_cfg<256, 192, 4, 2>(g, s);
         return launch_cfg<128, 128, 2, 2>(g, s);
     }
-    switch (gemm_bf16_tile_big(g.M, g.N, g.split_k)) {
+    switch (gemm_bf16_tile_big(g.M, g.N, g.split_k, g.b_mode == OP_KS)) {
         case 2: return gemm_bf16_pipe(g, 0, s);               // 256 x 192, 4 waves, phase-pipelined
         case 3: return gemm_bf16_pipe(g, 1, s);               // 256 x 256, 8 waves, phase-pipelined
         case 1: return launch_cfg<256, 192, 4, 2>(g, s);      // 256 x 192, 8 waves, one barrier per K-tile
+        case 4: return launch_cfg<128, 192, 2, 2>(g, s);      // 128 x 192, 4 waves, 80 KiB LDS: two workgroups per CU
         default: return launch_cfg<128, 128, 2, 2>(g, s);
     }
 }

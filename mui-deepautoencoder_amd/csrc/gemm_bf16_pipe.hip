@@ -114,8 +114,9 @@ __device__ __forceinline__ int ks_from_lds_block(int lds_block, int kr) {
 template <int MODE, int RH, int S, int NW>
 __device__ __forceinline__ void stage_half(lds_char* img, const bf16_t* __restrict__ P, int64_t ld, int r0, int rmax,
                                            int k0, int h, int w, int lane) {
+    // NW here = number of LOADER waves of this half-tile (waves w >= NW do not call)
     constexpr int NI = RH / 8 / NW;
-    static_assert(NI * NW * 8 == RH, "half-tile must split evenly over the waves");
+    static_assert(NI * NW * 8 == RH, "half-tile must split evenly over the loader waves");
 #pragma unroll
     for (int it = 0; it < NI; ++it) {
         const int j = it * NW + w;
@@ -159,7 +160,7 @@ __device__ __forceinline__ bf16x8 read_frag(const lds_char* img, int t, int s, i
     }
 }
 
-template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, bool C_F32, int DBG = 0>
+template <int BM, int BN, int WM, int WN, int NLB, int A_MODE, int B_MODE, bool C_F32, int DBG = 0>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4)
 void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
     constexpr int NW = WM * WN;
@@ -168,7 +169,10 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
     constexpr int TMH = SM / 32, TNH = SN / 32;      // 16-wide MFMA tiles per wave half
     constexpr int AH = AHR * 128, BH = BHR * 128;    // bytes per half image
     constexpr int BUF = 2 * AH + 2 * BH;
-    constexpr int NA = AHR / 8 / NW, NB = BHR / 8 / NW;   // LDS-DMA instructions per wave per half-tile
+    // LDS-DMA instructions per wave per half-tile; the B half-tile may be loaded by the first NLB
+    // waves only (256 x 192 with 8 waves: 12 instructions = 6 waves x 2), the others issue none
+    constexpr int NA = AHR / 8 / NW, NB = BHR / 8 / NLB;
+    static_assert(NLB <= NW, "loader waves");
     static_assert(SM % 32 == 0 && SN % 32 == 0, "wave sub-tile must split into 16-wide half tiles");
     __shared__ __attribute__((aligned(16))) char smem_raw[2 * BUF];
     lds_char* smem = (lds_char*)smem_raw;
@@ -207,7 +211,8 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
     auto issue_b = [&](int tile, int h) {
         if constexpr (!dbg_noload) {
             const int src = tile < nkt ? tile : nkt - 1;
-            stage_half<B_MODE, BHR, SN, NW>(b_img(tile, h), g.B, g.ldb, j0, g.N, (kt_begin + src) * BK, h, w, lane);
+            if (NLB == NW || w < NLB)
+                stage_half<B_MODE, BHR, SN, NLB>(b_img(tile, h), g.B, g.ldb, j0, g.N, (kt_begin + src) * BK, h, w, lane);
         }
     };
 
@@ -256,7 +261,9 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
                     acc[mh][mt][nh][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nt][s], a[mt][s], acc[mh][mt][nh][nt], 0, 0, 0);
     };
     // the half this phase reads has landed once at most the 6 half-tiles issued after it are in flight
-    auto wait_half = [&]() { wait_vmcnt<3 * NA + 3 * NB>(); };
+    auto wait_half = [&]() {
+        if (NLB == NW || w < NLB) wait_vmcnt<3 * NA + 3 * NB>(); else wait_vmcnt<3 * NA>();
+    };
 
     // prologue = phases P3(-1), P4(-1) without MFMAs
     issue_a(0, 0); issue_b(0, 0); issue_a(0, 1); issue_b(0, 1);
@@ -281,28 +288,28 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
         issue_b(t + 2, 0);
         read_a(a1, t, 1);
         mma(a0, b0, 0, 0);
-        interleave<N_MMA, RD_A, NB>();
+        if constexpr (NW == 4) interleave<N_MMA, RD_A, NB>();
         // P2: A1 x B0
         wait_half();
         phase_barrier();
         issue_a(t + 2, 1);
         read_b(b1, t, 1);
         mma(a1, b0, 1, 0);
-        interleave<N_MMA, RD_B, NA>();
+        if constexpr (NW == 4) interleave<N_MMA, RD_B, NA>();
         // P3: A1 x B1
         wait_half();
         phase_barrier();
         issue_b(t + 2, 1);
         read_a(a0n, t + 1, 0);
         mma(a1, b1, 1, 1);
-        interleave<N_MMA, RD_A, NB>();
+        if constexpr (NW == 4) interleave<N_MMA, RD_A, NB>();
         // P4: A0 x B1
         wait_half();
         phase_barrier();
         issue_a(t + 3, 0);
         read_b(b0, t + 1, 0);
         mma(a0, b1, 0, 1);
-        interleave<N_MMA, RD_B, NA>();
+        if constexpr (NW == 4) interleave<N_MMA, RD_B, NA>();
     };
     int t = 0;
     for (; t + 1 < nkt; t += 2) {
@@ -386,7 +393,7 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
         }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NLB>
 int launch_pipe(const GemmBf16& g, hipStream_t s) {
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
     const int kt_total = g.K / BK;
@@ -394,7 +401,7 @@ int launch_pipe(const GemmBf16& g, hipStream_t s) {
     CODAE_REQUIRE(nwg < (1 << 30), "gemm_bf16: grid too large");
     dim3 grid((unsigned)nwg), block(64 * WM * WN);
 #define LAUNCH(AM, BMODE, CF) \
-    hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, WM, WN, AM, BMODE, CF>), grid, block, 0, s, g, tiles_n, tiles_m * tiles_n, kt_total)
+    hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, WM, WN, NLB, AM, BMODE, CF>), grid, block, 0, s, g, tiles_n, tiles_m * tiles_n, kt_total)
     if (g.a_mode == OP_KC && g.b_mode == OP_KC) { if (g.c_f32) LAUNCH(OP_KC, OP_KC, true); else LAUNCH(OP_KC, OP_KC, false); }
     else if (g.a_mode == OP_KC && g.b_mode == OP_KS) { if (g.c_f32) LAUNCH(OP_KC, OP_KS, true); else LAUNCH(OP_KC, OP_KS, false); }
     else if (g.a_mode == OP_KS && g.b_mode == OP_KS) { if (g.c_f32) LAUNCH(OP_KS, OP_KS, true); else LAUNCH(OP_KS, OP_KS, false); }
@@ -411,13 +418,13 @@ template <int DBG>
 int launch_dbg(const GemmBf16& g, hipStream_t s) {
     constexpr int BM = 256, BN = 192;
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, 2, 2, OP_KC, OP_KC, false, DBG>), dim3(tiles_m * tiles_n), dim3(256), 0, s, g,
+    hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, 2, 2, 4, OP_KC, OP_KC, false, DBG>), dim3(tiles_m * tiles_n), dim3(256), 0, s, g,
                        tiles_n, tiles_m * tiles_n, g.K / BK);
     CODAE_LAUNCH_CHECK();
     return CODAE_OK;
 }
 
-// cfg 0: 256 x 192; cfg 1: 256 x 256 (both 2 x 2 waves)
+// cfg 0: 256 x 192 with 4 waves; cfg 1: 256 x 192 with 8 waves
 int gemm_bf16_pipe(const GemmBf16& g, int cfg, hipStream_t s) {
     if (g.dbg && g.a_mode == OP_KC && g.b_mode == OP_KC && !g.c_f32 && g.split_k == 1) {
         switch (g.dbg) {
@@ -431,8 +438,8 @@ int gemm_bf16_pipe(const GemmBf16& g, int cfg, hipStream_t s) {
             default: break;
         }
     }
-    if (cfg == 1) return launch_pipe<256, 256, 2, 2>(g, s);
-    return launch_pipe<256, 192, 2, 2>(g, s);
+    if (cfg == 1) return launch_pipe<256, 192, 4, 2, 6>(g, s);   // 8 waves (64 x 96 per wave), B halves by 6 loader waves
+    return launch_pipe<256, 192, 2, 2, 4>(g, s);                 // 4 waves (128 x 96 per wave)
 }
 
 }  // namespace codae

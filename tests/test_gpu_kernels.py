@@ -118,7 +118,7 @@ def ints(shape, g, lo=-3, hi=4):
 SHAPES_BF16 = [(128, 128, 64), (64, 64, 64), (200, 192, 128), (256, 384, 384), (1000, 832, 128), (8, 64, 64), (520, 448, 192)]
 
 
-@pytest.fixture(params=["s", "b", "p", "q"], ids=["tile128x128", "tile256x192", "pipe256x192w4", "pipe256x256w8"])
+@pytest.fixture(params=["s", "b", "c", "p", "q"], ids=["tile128x128", "tile256x192", "tile128x192x2", "pipe256x192w4", "pipe256x192w8"])
 def tile(request, monkeypatch):
     """force the small / big workgroup tile of the bf16 GEMM (CODAE_GEMM_TILE is read per launch)"""
     monkeypatch.setenv("CODAE_GEMM_TILE", request.param)
