@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libcodae_hip.so")
 PREC_F32 = 0
 PREC_BF16 = 1
 
-S_SQ_FULL, S_SQ_PARTIAL, S_GRAD_SQ, S_LAST_LOSS, S_STEP_SQ, S_COUNT = 0, 1, 2, 3, 4, 8
+S_SQ_FULL, S_SQ_PARTIAL, S_GRAD_SQ, S_LAST_LOSS, S_STEP_SQ, S_GRAD_SQ_SLOTS, S_N_SLOTS, S_COUNT = 0, 1, 2, 3, 4, 8, 64, 72
 KERNEL_CLASSES = ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "loss", "gather", "sumsq", "adam", "slab_reduce")
 
 

@@ -7,7 +7,8 @@ import ctypes as C
 
 import torch
 
-from . import (PREC_BF16, PREC_F32, S_COUNT, S_GRAD_SQ, S_LAST_LOSS, S_SQ_FULL, S_SQ_PARTIAL, Batch, Buffers,
+from . import (PREC_BF16, PREC_F32, S_COUNT, S_GRAD_SQ, S_GRAD_SQ_SLOTS, S_LAST_LOSS, S_N_SLOTS, S_SQ_FULL, S_SQ_PARTIAL,
+               Batch, Buffers,
                HipError, Hyper, Sizes, Spec, check, current_stream, lib, ptr)
 
 
@@ -218,7 +219,8 @@ class DaeEngine:
     def read_scalars(self):
         """(sq_full, sq_partial, grad_sq, last_loss) — synchronises."""
         s = self.scalars.cpu()
-        return float(s[S_SQ_FULL]), float(s[S_SQ_PARTIAL]), float(s[S_GRAD_SQ]), float(s[S_LAST_LOSS])
+        gsq = float(s[S_GRAD_SQ]) + float(s[S_GRAD_SQ_SLOTS:S_GRAD_SQ_SLOTS + S_N_SLOTS].sum())
+        return float(s[S_SQ_FULL]), float(s[S_SQ_PARTIAL]), gsq, float(s[S_LAST_LOSS])
 
     def zero_metric_sums(self):
         self.scalars[:2].zero_()

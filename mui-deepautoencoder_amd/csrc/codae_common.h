@@ -121,7 +121,8 @@ int launch_mse_dense(const float* x, const float* y, const float* fmask, float* 
 int launch_sumsq(const float* g, int64_t n, double* out, hipStream_t s);
 int launch_clip_adam(float* p, float* g, float* m, float* v, int64_t n, const codae_hyper* hp,
                      const double* grad_sq, bf16_t* shadow, const int64_t* shadow_map, hipStream_t s);
-int launch_reduce_slabs(const float* slabs, int n_slabs, int64_t slab_stride, float* out, int64_t n, hipStream_t s);
+int launch_reduce_slabs(const float* slabs, int n_slabs, int64_t slab_stride, float* out, int64_t n, double* sumsq,
+                        hipStream_t s);
 int launch_finish_loss(double* scalars, double inv_n, hipStream_t s);
 int launch_cast_f32(const bf16_t* src, float* dst, int64_t n, hipStream_t s);
 // out[n] += sum_m src[m][n]

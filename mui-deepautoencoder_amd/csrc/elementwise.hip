@@ -243,10 +243,13 @@ __global__ __launch_bounds__(NT) void mse_dense_kernel(const float* __restrict__
 
 // LAST_LOSS = STEP_SQ * inv_n ; reset the per-step accumulators
 __global__ void finish_loss_kernel(double* scalars, double inv_n) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        scalars[CODAE_S_LAST_LOSS] = scalars[CODAE_S_STEP_SQ] * inv_n;
-        scalars[CODAE_S_STEP_SQ] = 0.0;
-        scalars[CODAE_S_GRAD_SQ] = 0.0;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) {
+            scalars[CODAE_S_LAST_LOSS] = scalars[CODAE_S_STEP_SQ] * inv_n;
+            scalars[CODAE_S_STEP_SQ] = 0.0;
+            scalars[CODAE_S_GRAD_SQ] = 0.0;
+        }
+        if (threadIdx.x < CODAE_S_N_SLOTS) scalars[CODAE_S_GRAD_SQ_SLOTS + threadIdx.x] = 0.0;
     }
 }
 
@@ -262,7 +265,9 @@ __global__ __launch_bounds__(NT) void sumsq_kernel(const float* __restrict__ g, 
     for (int64_t e = n4 * 4 + (int64_t)blockIdx.x * NT + threadIdx.x; e < n; e += (int64_t)gridDim.x * NT)
         s += g[e] * g[e];
     const float b = block_sum(s, red);
-    if (threadIdx.x == 0) atomicAdd(out, (double)b);
+    // `out` points at scalars[GRAD_SQ]; scatter over the slot array that follows the named scalars
+    if (threadIdx.x == 0)
+        atomicAdd(out + (CODAE_S_GRAD_SQ_SLOTS - CODAE_S_GRAD_SQ) + (blockIdx.x & (CODAE_S_N_SLOTS - 1)), (double)b);
 }
 
 // ---- a7 + a8: clip scale folded into Adam (torch.optim.Adam, amsgrad off, L2 decay) ----------
@@ -284,7 +289,16 @@ __global__ __launch_bounds__(NT) void clip_adam_kernel(float* __restrict__ p, co
                                                        bf16_t* __restrict__ shadow) {
     float coef = 1.f;
     if (c.max_norm > 0.f) {
-        const float total = sqrtf((float)(*grad_sq));
+        // sum g^2 = scalars[GRAD_SQ] + its 64 partial slots (one wave adds them up, LDS broadcasts)
+        __shared__ double total_sq;
+        if (threadIdx.x < 64) {
+            double v = grad_sq[(CODAE_S_GRAD_SQ_SLOTS - CODAE_S_GRAD_SQ) + threadIdx.x];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (threadIdx.x == 0) total_sq = v + grad_sq[0];
+        }
+        __syncthreads();
+        const float total = sqrtf((float)total_sq);
         coef = fminf(1.f, c.max_norm / (total + 1e-6f));
     }
     const int64_t n4 = n / 4;  // n is padded to a multiple of 64 by the engine; tail handled below anyway
@@ -310,9 +324,13 @@ __global__ __launch_bounds__(NT) void clip_adam_kernel(float* __restrict__ p, co
     }
 }
 
-// out[i] = sum_s slabs[s][i]  (split-K partials of the weight-gradient GEMM)
+// out[i] = sum_s slabs[s][i]  (split-K partials of the weight-gradient GEMM); optionally also
+// sumsq += sum out[i]^2 so that clip_grad_norm_ needs no second pass over the gradient
 __global__ __launch_bounds__(NT) void reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs,
-                                                          int64_t stride, float* __restrict__ out, int64_t n) {
+                                                          int64_t stride, float* __restrict__ out, int64_t n,
+                                                          double* __restrict__ sumsq) {
+    __shared__ float red[4];
+    float sq = 0.f;
     const int64_t n4 = n / 4;
     for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < n4; e += (int64_t)gridDim.x * NT) {
         float4 a = reinterpret_cast<const float4*>(slabs)[e];
@@ -321,11 +339,18 @@ __global__ __launch_bounds__(NT) void reduce_slabs_kernel(const float* __restric
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
         }
         reinterpret_cast<float4*>(out)[e] = a;
+        sq += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
     }
     for (int64_t e = n4 * 4 + (int64_t)blockIdx.x * NT + threadIdx.x; e < n; e += (int64_t)gridDim.x * NT) {
         float a = slabs[e];
         for (int s = 1; s < n_slabs; ++s) a += slabs[s * stride + e];
         out[e] = a;
+        sq += a * a;
+    }
+    if (sumsq != nullptr) {
+        const float bsq = block_sum(sq, red);
+        if (threadIdx.x == 0)
+            atomicAdd(sumsq + (CODAE_S_GRAD_SQ_SLOTS - CODAE_S_GRAD_SQ) + (blockIdx.x & (CODAE_S_N_SLOTS - 1)), (double)bsq);
     }
 }
 
@@ -463,9 +488,10 @@ int launch_colsum_f32(const float* src, int M, int N, float* out, hipStream_t s)
     return CODAE_OK;
 }
 
-int launch_reduce_slabs(const float* slabs, int n_slabs, int64_t stride, float* out, int64_t n, hipStream_t s) {
+int launch_reduce_slabs(const float* slabs, int n_slabs, int64_t stride, float* out, int64_t n, double* sumsq,
+                        hipStream_t s) {
     CODAE_REQUIRE(slabs && out && n_slabs >= 1 && n > 0, "reduce_slabs: bad args");
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, s, slabs, n_slabs, stride, out, n);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, s, slabs, n_slabs, stride, out, n, sumsq);
     CODAE_LAUNCH_CHECK();
     return CODAE_OK;
 }

@@ -39,6 +39,8 @@ struct codae_engine {
     int64_t act_bytes = 0, dact_one = 0, slab_bytes = 0;
     std::vector<int> split_k;
     // optional per-launch hipEvent pairs (codae_profile_begin / _end)
+    // single-GPU fused step: the slab reduce of every layer also accumulates sum g^2 (clip_grad_norm_)
+    mutable bool norm_in_backward = false;
     mutable bool prof_on = false;
     mutable uint32_t prof_mask = 0;
     mutable int prof_n = 0;
@@ -152,7 +154,8 @@ int run_wgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, hi
             }
             if (rc) return rc;
             ProfScope prof(e, CODAE_K_SLAB_REDUCE, s);
-            return launch_reduce_slabs(reinterpret_cast<const float*>(b->slabs), S, (int64_t)N * K, dW, (int64_t)N * K, s);
+            return launch_reduce_slabs(reinterpret_cast<const float*>(b->slabs), S, (int64_t)N * K, dW, (int64_t)N * K,
+                                       e->norm_in_backward ? b->scalars + CODAE_S_GRAD_SQ : nullptr, s);
         }
         g.C = dW;
         ProfScope prof(e, CODAE_K_GEMM_WGRAD, s);
@@ -504,14 +507,20 @@ int codae_step_backward(codae_handle h, const codae_buffers* b, int32_t B, int32
     return backward_range(h, b, B, layer_lo, layer_hi, nullptr, true, (hipStream_t)stream);
 }
 
-int codae_step_update(codae_handle h, const codae_buffers* b, const codae_hyper* hyper, void* stream) {
+static int update_impl(codae_handle h, const codae_buffers* b, const codae_hyper* hyper, hipStream_t s, bool weights_norm_done) {
     CODAE_REQUIRE(h && b && hyper, "codae_step_update: null argument");
     CODAE_REQUIRE(b->params && b->grads && b->adam_m && b->adam_v && b->scalars, "codae_step_update: buffer missing");
-    hipStream_t s = (hipStream_t)stream;
     if (hyper->max_grad_norm > 0.f) {
-        CODAE_HIP_CHECK(hipMemsetAsync(b->scalars + CODAE_S_GRAD_SQ, 0, sizeof(double), s));
         ProfScope prof(h, CODAE_K_SUMSQ, s);
-        int rc = launch_sumsq(b->grads, h->n_param, b->scalars + CODAE_S_GRAD_SQ, s);
+        int rc;
+        if (weights_norm_done) {
+            // sum g^2 of every weight gradient was accumulated by the slab reduces: add the bias block
+            rc = launch_sumsq(b->grads + h->bias_begin, h->n_param - h->bias_begin, b->scalars + CODAE_S_GRAD_SQ, s);
+        } else {
+            CODAE_HIP_CHECK(hipMemsetAsync(b->scalars + CODAE_S_GRAD_SQ, 0, sizeof(double), s));
+            CODAE_HIP_CHECK(hipMemsetAsync(b->scalars + CODAE_S_GRAD_SQ_SLOTS, 0, CODAE_S_N_SLOTS * sizeof(double), s));
+            rc = launch_sumsq(b->grads, h->n_param, b->scalars + CODAE_S_GRAD_SQ, s);
+        }
         if (rc) return rc;
     }
     ProfScope prof(h, CODAE_K_ADAM, s);
@@ -521,13 +530,25 @@ int codae_step_update(codae_handle h, const codae_buffers* b, const codae_hyper*
                             shadow, nullptr, s);
 }
 
+int codae_step_update(codae_handle h, const codae_buffers* b, const codae_hyper* hyper, void* stream) {
+    return update_impl(h, b, hyper, (hipStream_t)stream, false);
+}
+
 int codae_train_step(codae_handle h, const codae_buffers* b, const codae_batch* batch, const codae_hyper* hyper, void* stream) {
     CODAE_REQUIRE(hyper != nullptr, "codae_train_step: null hyper");
     int rc = codae_step_forward_loss(h, b, batch, hyper, nullptr, stream);
     if (rc) return rc;
+    // single GPU: nothing happens to the gradients between backward and update, so the norm can be
+    // gathered while the split-K slabs are reduced (finish_loss zeroed GRAD_SQ before the backward)
+    const int rows = h->rows_for(batch->B);
+    bool all_slabbed = h->prec == CODAE_PREC_BF16 && hyper->max_grad_norm > 0.f && getenv("CODAE_NO_FUSED_NORM") == nullptr;
+    for (int l = 0; l < h->L && all_slabbed; ++l)
+        if ((h->split_k[l] <= rows / 64 ? h->split_k[l] : rows / 64) <= 1) all_slabbed = false;
+    h->norm_in_backward = all_slabbed;
     rc = codae_step_backward(h, b, batch->B, 0, h->L, stream);
+    h->norm_in_backward = false;
     if (rc) return rc;
-    return codae_step_update(h, b, hyper, stream);
+    return update_impl(h, b, hyper, (hipStream_t)stream, all_slabbed);
 }
 
 // ---- stand-alone ops --------------------------------------------------------------------
@@ -554,6 +575,7 @@ int codae_clip_adam(float* params, float* grads, float* adam_m, float* adam_v, i
     hipStream_t s = (hipStream_t)stream;
     if (hyper->max_grad_norm > 0.f) {
         CODAE_HIP_CHECK(hipMemsetAsync(scalars + CODAE_S_GRAD_SQ, 0, sizeof(double), s));
+        CODAE_HIP_CHECK(hipMemsetAsync(scalars + CODAE_S_GRAD_SQ_SLOTS, 0, CODAE_S_N_SLOTS * sizeof(double), s));
         int rc = launch_sumsq(grads, n, scalars + CODAE_S_GRAD_SQ, s);
         if (rc) return rc;
     }
@@ -635,7 +657,7 @@ int codae_wgrad_bf16(const void* dy, const void* x, float* dW, void* slabs, int6
     g.C = S > 1 ? slabs : (void*)dW;
     int rc = gemm_bf16(g, (hipStream_t)stream);
     if (rc) return rc;
-    if (S > 1) return launch_reduce_slabs(reinterpret_cast<const float*>(slabs), S, (int64_t)N * K, dW, (int64_t)N * K, (hipStream_t)stream);
+    if (S > 1) return launch_reduce_slabs(reinterpret_cast<const float*>(slabs), S, (int64_t)N * K, dW, (int64_t)N * K, nullptr, (hipStream_t)stream);
     return CODAE_OK;
 }
 

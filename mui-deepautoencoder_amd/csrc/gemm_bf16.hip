@@ -410,25 +410,49 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
         }
         return;
     }
-    char* Cbase = reinterpret_cast<char*>(g.C);
-    if (g.split_k > 1) Cbase += (int64_t)z * g.M * g.ldc * sizeof(float);
+    // fp32 output (split-K slabs of the weight gradient, fp32 y): same idea as the bf16 path, in two
+    // row halves because the fp32 tile is twice the staging space; 16 B per lane, whole rows.
+    {
+        constexpr int NT = 64 * NW;
+        constexpr int HR = BM / 2;
+        constexpr int PITCH = BN * 4 + 16;
+        static_assert(HR * PITCH <= 2 * BUF_BYTES, "fp32 half tile must fit in the staging buffers");
+        static_assert((BM / WM) <= HR, "a wave's rows must lie in one half");
+        constexpr int CH = BN / 4, RL = NT / CH;          // float4 chunks per row, rows per pass
+        float* Cf = reinterpret_cast<float*>(g.C);
+        if (g.split_k > 1) Cf += (int64_t)z * g.M * g.ldc;
+        const int c = threadIdx.x % CH, rl = threadIdx.x / CH;
+        const int j = j0 + c * 4;
 #pragma unroll
-    for (int nt = 0; nt < TN; ++nt) {
-        const int j = j0 + (BN / WN) * wc + 16 * nt + g4;
-        const bool jok = j < g.N;   // N is a multiple of 8 and j of 4: j < N => j + 3 < N
-        float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g.bias != nullptr && jok) bj = *reinterpret_cast<const float4*>(g.bias + j);
+        for (int hh = 0; hh < 2; ++hh) {
+            if (((BM / WM) * wr) / HR == hh) {
 #pragma unroll
-        for (int mt = 0; mt < TM; ++mt) {
-            const int i = i0 + (BM / WM) * wr + 16 * mt + li;
-            if (i < g.M && jok) {
-                float v0 = acc[mt][nt][0] + bj.x, v1 = acc[mt][nt][1] + bj.y;
-                float v2 = acc[mt][nt][2] + bj.z, v3 = acc[mt][nt][3] + bj.w;
-                if (g.relu) {
-                    v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+                for (int nt = 0; nt < TN; ++nt) {
+                    const int jl = (BN / WN) * wc + 16 * nt + g4;
+                    float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (g.bias != nullptr && j0 + jl < g.N) bj = *reinterpret_cast<const float4*>(g.bias + j0 + jl);
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt) {
+                        const int il = (BM / WM) * wr + 16 * mt + li - hh * HR;
+                        f32x4 v = acc[mt][nt];
+                        v[0] += bj.x; v[1] += bj.y; v[2] += bj.z; v[3] += bj.w;
+                        if (g.relu) {
+                            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                        }
+                        *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(smem + il * PITCH + jl * 4) = v;
+                    }
                 }
-                *reinterpret_cast<float4*>(Cbase + ((int64_t)i * g.ldc + j) * 4) = make_float4(v0, v1, v2, v3);
             }
+            __syncthreads();
+            if (rl < RL && j < g.N) {
+                for (int r = rl; r < HR; r += RL) {
+                    const int i = i0 + hh * HR + r;
+                    if (i >= g.M) break;
+                    const f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(smem + r * PITCH + c * 16);
+                    *reinterpret_cast<float4*>(Cf + (int64_t)i * g.ldc + j) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+            __syncthreads();
         }
     }
 }

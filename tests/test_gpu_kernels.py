@@ -240,7 +240,7 @@ def test_clip_adam_matches_torch(hip, n):
     ref_p = torch.nn.Parameter(p0.clone().double())
     opt = torch.optim.Adam([ref_p], lr=1e-3, weight_decay=1e-2)
     p = p0.clone().to(dev()); m = torch.zeros(n, device=dev()); v = torch.zeros(n, device=dev())
-    sc = torch.zeros(8, dtype=torch.float64, device=dev())
+    sc = torch.zeros(hip.S_COUNT, dtype=torch.float64, device=dev())
     for step in range(1, 4):
         grad = g0 * step
         ref_p.grad = grad.clone().double()
@@ -250,7 +250,8 @@ def test_clip_adam_matches_torch(hip, n):
         hp = hip.Hyper(1e-3, 1e-2, 0.9, 0.999, 1e-8, 1.0, step, 0.0)
         hip.check(hip.lib().codae_clip_adam(hip.ptr(p), hip.ptr(gd), hip.ptr(m), hip.ptr(v), n, C.byref(hp), hip.ptr(sc), hip.current_stream()))
         sync()
-        assert abs(float(sc[hip.S_GRAD_SQ]) ** 0.5 - float(total)) < 1e-4 * float(total) + 1e-6
+        gsq = float(sc[hip.S_GRAD_SQ]) + float(sc[hip.S_GRAD_SQ_SLOTS:hip.S_GRAD_SQ_SLOTS + hip.S_N_SLOTS].sum())
+        assert abs(gsq ** 0.5 - float(total)) < 1e-4 * float(total) + 1e-6
         assert np.allclose(f64(p), f64(ref_p), rtol=1e-3, atol=1e-5)
 
 
@@ -260,7 +261,7 @@ def test_mse_loss_dense(hip):
     x = rng.random((B, io), dtype=np.float32); y = rng.random((B, io), dtype=np.float32)
     fm = (rng.random((B, io)) > 0.3).astype(np.float32)
     xd, yd, fd = (torch.tensor(a, device=dev()) for a in (x, y, fm))
-    dy = torch.empty_like(xd); sc = torch.zeros(8, dtype=torch.float64, device=dev())
+    dy = torch.empty_like(xd); sc = torch.zeros(hip.S_COUNT, dtype=torch.float64, device=dev())
     hip.check(hip.lib().codae_mse_loss_fwd_bwd(hip.ptr(xd), hip.ptr(yd), hip.ptr(fd), hip.ptr(dy), B * io, 1.0 / (B * io), hip.ptr(sc), hip.current_stream()))
     sync()
     d = x.astype(np.float64) - y
