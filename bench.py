@@ -15,9 +15,10 @@ GEMMs, MSE loss+grad+metric sums, 10 weight-gradient + 9 data-gradient GEMMs, gr
 Adam + bf16 shadow refresh); with N > 1 the gradient buckets are all-reduced over RCCL between
 backward and update, overlapped with the remaining backward GEMMs.
 
-One JSON line on rank 0.  `roofline`: the GEMM class that takes the most time per step, timed
+One JSON line on rank 0.  `roofline`: the forward GEMM class (the 3-slot x 512 encoder GEMM), timed
 with hipEvent pairs recorded around every launch of the timed region on the launch stream
-(codae_profile_begin/_end); achieved = 2*M*N*K / mean launch time.  `cpu_baseline`: the numpy
+(codae_profile_begin/_end); achieved = 2*M*N*K / mean launch time.  (dgrad and wgrad launches of a
+layer run concurrently on two streams; their overlapping times are listed under by_kernel.)  `cpu_baseline`: the numpy
 oracle (oracle/dae_oracle.py, a port of the reference's math; used here only as the thing timed)
 on the host cores, bounded sample.
 """
