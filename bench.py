@@ -127,10 +127,15 @@ def main():
         sys.exit("bench.py needs a GPU (libcodae_hip.so has no CPU path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    distributed = world > 1
+    # BENCH_FORCE_DIST=1: initialise the process group and run the bucketed all-reduce path even with one
+    # rank (rehearsal of the multi-GPU launch on a single-GPU box)
+    distributed = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
     from codae.train import HipEmbeddingTrainer

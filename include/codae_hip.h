@@ -202,6 +202,26 @@ int codae_mse_loss_fwd_bwd(const float* x, const float* y, const float* fmask, f
 int codae_clip_adam(float* params, float* grads, float* adam_m, float* adam_v, int64_t n,
                     const codae_hyper* hyper, double* scalars, void* stream);
 
+/* ---- "next" rows: abalone loss and validation rank metric ---- */
+/* CombinedCriterion(reduction="mean") forward + gradient (codae/tool/metering.py:155-180): per variable v with
+ * span [var_pos[v], +var_size[v]): type 0 regression -> w_v * sqrt(mean (x-y)^2), type 1 classification ->
+ * w_v * mean_B NLL(log_softmax(y_span), argmax x_span); loss = sum / n_var.  acc: n_var doubles of scratch;
+ * dy [B][io] (may be NULL), loss_out: one double. */
+int codae_combined_loss_fwd_bwd(const float* x, const float* y, int32_t B, int32_t io, int32_t n_var, const int32_t* var_pos,
+                                const int32_t* var_size, const int32_t* var_type, const float* var_weight, double* acc,
+                                float* dy, double* loss_out, void* stream);
+/* CombinedCriterion(reduction="none") (metering.py:131-152): out[B][n_var] = squared error (size-1 regression) or NLL */
+int codae_combined_loss_full(const float* x, const float* y, int32_t B, int32_t io, int32_t n_var, const int32_t* var_pos,
+                             const int32_t* var_size, const int32_t* var_type, float* out, void* stream);
+/* out[r] = ||m[r][:]||_2 */
+int codae_row_norms(const float* m, int64_t rows, int32_t E, float* out, void* stream);
+/* RankingLoss.get (metering.py:46-79): *out += sum_b 1 - rank_b / (n_val - 1); inventory [n_slots][n_obs][E] =
+ * dataset.data_per_category (unscaled), inventory_norm [n_slots][n_obs] its row norms, idx[B] dataset index of
+ * each sample, val_idx[n_val] the validation indices. */
+int codae_ranking_loss(const float* pred, const float* fmask, const int32_t* idx, int32_t B, int32_t io, int32_t n_slots,
+                       int32_t E, const float* inventory, const float* inventory_norm, int64_t n_obs, const int32_t* val_idx,
+                       int32_t n_val, double* out, void* stream);
+
 /* ---- GEMM primitives (exported for kernel-level parity tests / benchmarks) - */
 /* y[M][N] = act(x[M][K] . W[N][K]^T + b[N]), fp32, exact-fp32 MFMA */
 int codae_linear_f32(const float* x, const float* W, const float* b, float* y, int32_t M, int32_t N,

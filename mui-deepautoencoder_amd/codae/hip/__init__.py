@@ -77,6 +77,10 @@ PROTOTYPES = {
     "codae_expand_masks": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "codae_mse_loss_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _F, _P, _P]),
     "codae_clip_adam": (C.c_int, [_P, _P, _P, _P, _I64, C.POINTER(Hyper), _P, _P]),
+    "codae_combined_loss_fwd_bwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "codae_combined_loss_full": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
+    "codae_row_norms": (C.c_int, [_P, _I64, _I32, _P, _P]),
+    "codae_ranking_loss": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _I64, _P, _I32, _P, _P]),
     "codae_linear_f32": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "codae_dgrad_f32": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _P]),
     "codae_wgrad_f32": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _P]),

@@ -1,15 +1,32 @@
 """Criteria and metrics of `codae.tool` (codae/tool/metering.py:24-204 of the reference).
 
-CombinedCriterion and RankingLoss keep the reference's call signatures and numerics.  They are
-the abalone loss and the validation-only rank metric — rows "next" of the scope table (SURVEY.md
-section 8f) — and are expressed here as whole-tensor torch operations on the tensors' own device
-(no per-sample Python loops); the MSE training loss of the embedding path is the fused HIP
-kernel (codae_mse_loss_fwd_bwd / codae_step_forward_loss).
+CombinedCriterion (the abalone loss) and RankingLoss (the validation-only rank metric) keep the
+reference's call signatures and numerics.  With tensors on a HIP device they run as kernels of
+libcodae_hip.so (criteria.hip: codae_combined_loss_fwd_bwd / _full, codae_ranking_loss); with host
+tensors (which upstream also accepts) they are whole-tensor torch expressions, no per-sample loops.
 """
+import ctypes as C
+
 import numpy as np
 import torch
 
+from ..hip import check as _check, current_stream as _stream, lib as _hip_lib, ptr as _ptr
 from .batching import get_mask_transformation
+
+
+class _CombinedMeanFn(torch.autograd.Function):
+    """loss = CombinedCriterion mean loss; d loss / d y from the same kernel pass."""
+
+    @staticmethod
+    def forward(ctx, y, x, crit):
+        loss, dy = crit._hip_mean(x, y.detach())
+        ctx.save_for_backward(dy)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dy,) = ctx.saved_tensors
+        return g * dy, None, None
 
 
 def get_rmse(x, y):
@@ -28,7 +45,31 @@ class RankingLoss:
         self.validation_indices = validation_indices
         self._val = None
 
+    def _get_hip(self, prediction, fmask, indices):
+        ds = self.dataset
+        dev = prediction.device
+        S, E = ds.nb_used_category, ds.embedding_size
+        if getattr(self, "_inv", None) is None or self._inv.device != dev:
+            self._inv = torch.stack([ds.data_per_category[c].to(dev, torch.float32) for c in range(S)]).contiguous()
+            self._inv_norm = torch.empty(self._inv.shape[:2], dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _check(_hip_lib().codae_row_norms(_ptr(self._inv), S * self._inv.shape[1], E, _ptr(self._inv_norm), _stream()))
+            self._val_i32 = torch.as_tensor(list(self.validation_indices), dtype=torch.int32, device=dev)
+            self._out = torch.zeros(1, dtype=torch.float64, device=dev)
+        idx = torch.as_tensor(list(indices), dtype=torch.int32, device=dev)
+        pred = prediction.detach().to(torch.float32).contiguous()
+        fm = fmask.to(device=dev, dtype=torch.float32).contiguous()
+        self._out.zero_()
+        with torch.cuda.device(dev):
+            _check(_hip_lib().codae_ranking_loss(_ptr(pred), _ptr(fm), _ptr(idx), pred.shape[0], pred.shape[1], S, E,
+                                                 _ptr(self._inv), _ptr(self._inv_norm), self._inv.shape[1],
+                                                 _ptr(self._val_i32), len(self.validation_indices), _ptr(self._out),
+                                                 _stream()))
+        return float(self._out.item())
+
     def get(self, prediction, fmask, indices):
+        if prediction.device.type == "cuda":
+            return self._get_hip(prediction, fmask, indices)
         E = self.dataset.embedding_size
         dev = prediction.device
         if self._val is None or self._val.device != dev:
@@ -78,6 +119,46 @@ class CombinedCriterion:
             return self._full_loss(x, y, as_numpy)
         raise Exception("Unknown reduction type.")
 
+    # ---- HIP path (tensors on a HIP device) -------------------------------------------------
+    def _tables(self, dev):
+        t = getattr(self, "_dev_tables", None)
+        if t is None or t[0].device != dev:
+            i32 = dict(dtype=torch.int32, device=dev)
+            w = self.weight.reshape(-1).to(torch.float32)
+            if w.numel() != len(self.arch):
+                raise Exception("CombinedCriterion: one weight per variable is required on the HIP path")
+            t = (torch.tensor([v["position"] for v in self.arch], **i32),
+                 torch.tensor([v["size"] for v in self.arch], **i32),
+                 torch.tensor([0 if v["type"] == "regression" else 1 for v in self.arch], **i32),
+                 w.to(dev).contiguous(),
+                 torch.zeros(len(self.arch), dtype=torch.float64, device=dev))
+            self._dev_tables = t
+        return t
+
+    def _hip_mean(self, x, y):
+        dev = y.device
+        pos, size, typ, w, acc = self._tables(dev)
+        x = x.detach().to(torch.float32).contiguous()
+        y = y.to(torch.float32).contiguous()
+        dy = torch.empty_like(y)
+        loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            _check(_hip_lib().codae_combined_loss_fwd_bwd(_ptr(x), _ptr(y), y.shape[0], y.shape[1], len(self.arch), _ptr(pos),
+                                                          _ptr(size), _ptr(typ), _ptr(w), _ptr(acc), _ptr(dy), _ptr(loss),
+                                                          _stream()))
+        return loss[0].to(torch.float32), dy
+
+    def _hip_full(self, x, y):
+        dev = y.device
+        pos, size, typ, _, _ = self._tables(dev)
+        x = x.detach().to(torch.float32).contiguous()
+        y = y.detach().to(torch.float32).contiguous()
+        out = torch.empty((y.shape[0], len(self.arch)), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _check(_hip_lib().codae_combined_loss_full(_ptr(x), _ptr(y), y.shape[0], y.shape[1], len(self.arch), _ptr(pos),
+                                                       _ptr(size), _ptr(typ), _ptr(out), _stream()))
+        return out
+
     def _per_variable(self, x, y, v):
         p, s = v["position"], v["size"]
         xs, ys = x[:, p:p + s], y[:, p:p + s]
@@ -86,6 +167,9 @@ class CombinedCriterion:
         return self.CE_criterion(input=torch.log_softmax(ys, dim=1), target=xs.max(dim=1)[1])
 
     def _full_loss(self, x, y, as_numpy=False):
+        if y.device.type == "cuda":
+            loss = self._hip_full(x, y).cpu()                   # upstream returns a host tensor (:133)
+            return loss.numpy() if as_numpy else loss
         loss = torch.zeros((x.size()[0], len(self.arch)))       # on the host, as upstream (:133)
         for i, v in enumerate(self.arch):
             li = self._per_variable(x, y, v)
@@ -98,6 +182,8 @@ class CombinedCriterion:
         return loss
 
     def _mean_loss(self, x, y, as_numpy=False):
+        if y.device.type == "cuda" and not as_numpy:
+            return _CombinedMeanFn.apply(y, x, self)
         loss = []
         for v in self.arch:
             li = self._per_variable(x, y, v)

@@ -43,10 +43,23 @@ class SubsetEpochSampler:
 
 
 def default_buckets(n_layers, n_buckets=4):
-    """[(lo, hi)] layer ranges in backward order, e.g. 10 layers -> (8,10) (5,8) (2,5) (0,2)."""
+    """[(lo, hi)] layer ranges in backward order, sizes decreasing: 10 layers -> (6,10) (3,6) (1,3) (0,1).
+    The first buckets' all-reduces hide under the remaining backward GEMMs; the last bucket's cannot, so it
+    is the smallest (one layer = 9.4 MB at 1536^2)."""
     n_buckets = max(1, min(n_buckets, n_layers))
-    edges = [round(n_layers * i / n_buckets) for i in range(n_buckets + 1)]
-    return [(edges[i], edges[i + 1]) for i in range(n_buckets - 1, -1, -1) if edges[i] < edges[i + 1]]
+    weights = list(range(n_buckets, 0, -1))                     # n, n-1, ..., 1
+    total = sum(weights)
+    sizes = [max(1, round(n_layers * w / total)) for w in weights]
+    while sum(sizes) > n_layers:                                # trim from the biggest
+        sizes[sizes.index(max(sizes))] -= 1
+    while sum(sizes) < n_layers:                                # pad the first (best hidden) bucket
+        sizes[0] += 1
+    out, hi = [], n_layers
+    for sz in sizes:
+        if sz > 0:
+            out.append((hi - sz, hi))
+            hi -= sz
+    return out
 
 
 class DataParallel:

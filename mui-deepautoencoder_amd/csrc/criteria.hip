@@ -1,0 +1,233 @@
+// "Next" rows of the scope table: the abalone training loss
+// (CombinedCriterion, codae/tool/metering.py:82-180 of the reference) and the validation rank
+// metric (RankingLoss, metering.py:29-79) as HIP kernels.  Small, HBM/latency-bound work: one pass
+// per kernel, no GEMM reshaping.
+#include "codae_common.h"
+
+namespace codae {
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// log-softmax of y[p .. p+s) evaluated at index t (numerically as torch.log_softmax)
+__device__ __forceinline__ float log_softmax_at(const float* __restrict__ yr, int p, int s, int t) {
+    float m = yr[p];
+    for (int k = 1; k < s; ++k) m = fmaxf(m, yr[p + k]);
+    float se = 0.f;
+    for (int k = 0; k < s; ++k) se += expf(yr[p + k] - m);
+    return (yr[p + t] - m) - logf(se);
+}
+__device__ __forceinline__ int argmax_first(const float* __restrict__ xr, int p, int s) {
+    int t = 0;
+    float best = xr[p];
+    for (int k = 1; k < s; ++k)
+        if (xr[p + k] > best) { best = xr[p + k]; t = k; }
+    return t;
+}
+
+// pass 1: acc[v] = sum over the batch of  sum_s (x-y)^2   (regression)
+//                                        -log_softmax(y)[argmax x]   (classification)
+__global__ __launch_bounds__(NT) void combined_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                             int B, int io, int nv, const int32_t* __restrict__ pos,
+                                                             const int32_t* __restrict__ size,
+                                                             const int32_t* __restrict__ type, double* __restrict__ acc) {
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < (int64_t)B * nv; e += (int64_t)gridDim.x * NT) {
+        const int b = (int)(e / nv), v = (int)(e - (int64_t)b * nv);
+        const float* xr = x + (int64_t)b * io;
+        const float* yr = y + (int64_t)b * io;
+        const int p = pos[v], s = size[v];
+        float val = 0.f;
+        if (type[v] == 0) {
+            for (int k = 0; k < s; ++k) { const float d = xr[p + k] - yr[p + k]; val += d * d; }
+        } else {
+            val = -log_softmax_at(yr, p, s, argmax_first(xr, p, s));
+        }
+        atomicAdd(&acc[v], (double)val);
+    }
+}
+
+// pass 2: loss = (1/nv) sum_v w_v L_v, L_v = sqrt(acc_v / (B s)) or acc_v / B; dy = dloss/dy
+__global__ __launch_bounds__(NT) void combined_grad_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           int B, int io, int nv, const int32_t* __restrict__ pos,
+                                                           const int32_t* __restrict__ size,
+                                                           const int32_t* __restrict__ type,
+                                                           const float* __restrict__ weight,
+                                                           const double* __restrict__ acc, float* __restrict__ dy,
+                                                           double* __restrict__ loss_out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double loss = 0.0;
+        for (int v = 0; v < nv; ++v) {
+            const double lv = type[v] == 0 ? sqrt(acc[v] / ((double)B * size[v])) : acc[v] / (double)B;
+            loss += (double)weight[v] * lv;
+        }
+        *loss_out = loss / nv;
+    }
+    if (dy == nullptr) return;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < (int64_t)B * nv; e += (int64_t)gridDim.x * NT) {
+        const int b = (int)(e / nv), v = (int)(e - (int64_t)b * nv);
+        const float* xr = x + (int64_t)b * io;
+        const float* yr = y + (int64_t)b * io;
+        float* gr = dy + (int64_t)b * io;
+        const int p = pos[v], s = size[v];
+        const float c = weight[v] / (float)nv;
+        if (type[v] == 0) {
+            const float rmse = (float)sqrt(acc[v] / ((double)B * s));
+            const float k0 = c / ((float)B * (float)s * rmse);
+            for (int k = 0; k < s; ++k) gr[p + k] = k0 * (yr[p + k] - xr[p + k]);
+        } else {
+            const int t = argmax_first(xr, p, s);
+            float m = yr[p];
+            for (int k = 1; k < s; ++k) m = fmaxf(m, yr[p + k]);
+            float se = 0.f;
+            for (int k = 0; k < s; ++k) se += expf(yr[p + k] - m);
+            for (int k = 0; k < s; ++k) gr[p + k] = c * (expf(yr[p + k] - m) / se - (k == t ? 1.f : 0.f)) / (float)B;
+        }
+    }
+}
+
+// monitor criterion (reduction "none", metering.py:131-152): out[b][v] = (x-y)^2 (size-1 regression) | NLL
+__global__ __launch_bounds__(NT) void combined_full_kernel(const float* __restrict__ x, const float* __restrict__ y, int B,
+                                                           int io, int nv, const int32_t* __restrict__ pos,
+                                                           const int32_t* __restrict__ size,
+                                                           const int32_t* __restrict__ type, float* __restrict__ out) {
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < (int64_t)B * nv; e += (int64_t)gridDim.x * NT) {
+        const int b = (int)(e / nv), v = (int)(e - (int64_t)b * nv);
+        const float* xr = x + (int64_t)b * io;
+        const float* yr = y + (int64_t)b * io;
+        const int p = pos[v], s = size[v];
+        float val;
+        if (type[v] == 0) { const float d = xr[p] - yr[p]; val = d * d; }
+        else val = -log_softmax_at(yr, p, s, argmax_first(xr, p, s));
+        out[e] = val;
+    }
+}
+
+// ||row||_2 of a [rows][E] matrix, one wave per row
+__global__ __launch_bounds__(NT) void row_norm_kernel(const float* __restrict__ m, int64_t rows, int E, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+        const float* p = m + r * E;
+        float s = 0.f;
+        for (int k = lane; k < E; k += 64) s += p[k] * p[k];
+        s = wave_sum_f(s);
+        if (lane == 0) out[r] = sqrtf(s);
+    }
+}
+
+// RankingLoss.get (metering.py:46-79): one workgroup per batch sample.
+//   c     = blanked slot = sum_s s * (1 - fmask[b][s*E])                       (metering.py:56)
+//   s_j   = cos(inventory[c][j], prediction[b][cE:(c+1)E])                      (:66-68)
+//   rank  = #{ j in validation : s[idx_b] > s_j }                               (:72-75)
+//   out  += 1 - rank / (V - 1)                                                  (:77)
+__global__ __launch_bounds__(NT) void ranking_kernel(const float* __restrict__ pred, const float* __restrict__ fmask,
+                                                     const int32_t* __restrict__ idx, int io, int S, int E,
+                                                     const float* __restrict__ inv, const float* __restrict__ inv_norm,
+                                                     int64_t n_obs, const int32_t* __restrict__ val, int V,
+                                                     double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float q[];   // [E] + 8 scratch
+    __shared__ float red[8];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int c = 0;
+    for (int s = 1; s < S; ++s) c += (fmask[(int64_t)b * io + (int64_t)s * E] == 0.f) ? s : 0;
+    const float* pq = pred + (int64_t)b * io + (int64_t)c * E;
+    float sq = 0.f;
+    for (int k = threadIdx.x; k < E; k += NT) { const float v = pq[k]; q[k] = v; sq += v * v; }
+    sq = wave_sum_f(sq);
+    if (lane == 0) red[w] = sq;
+    __syncthreads();
+    const float qn = fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), 1e-8f);
+    const float* invc = inv + (int64_t)c * n_obs * E;
+    const float* nrmc = inv_norm + (int64_t)c * n_obs;
+    // own similarity (every wave computes it: cheaper than another barrier)
+    const int64_t me = idx[b];
+    float d = 0.f;
+    for (int k = lane; k < E; k += 64) d += q[k] * invc[me * E + k];
+    d = wave_sum_f(d);
+    const float own = d / (qn * fmaxf(nrmc[me], 1e-8f));
+    int rank = 0;
+    for (int j = w; j < V; j += 4) {
+        const int64_t r = val[j];
+        const float* pr = invc + r * E;
+        float dj = 0.f;
+        for (int k = lane; k < E; k += 64) dj += q[k] * pr[k];
+        dj = wave_sum_f(dj);
+        const float sj = dj / (qn * fmaxf(nrmc[r], 1e-8f));
+        rank += (own > sj) ? 1 : 0;
+    }
+    __syncthreads();
+    if (lane == 0) red[4 + w] = (float)rank;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double total = (double)red[4] + red[5] + red[6] + red[7];
+        atomicAdd(out, 1.0 - total / (double)(V - 1));
+    }
+}
+
+inline int grid_for(int64_t items) {
+    int64_t b = (items + NT - 1) / NT;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+}  // namespace
+}  // namespace codae
+
+using namespace codae;
+
+extern "C" {
+
+int codae_combined_loss_fwd_bwd(const float* x, const float* y, int32_t B, int32_t io, int32_t n_var, const int32_t* var_pos,
+                                const int32_t* var_size, const int32_t* var_type, const float* var_weight, double* acc,
+                                float* dy, double* loss_out, void* stream) {
+    CODAE_REQUIRE(x && y && var_pos && var_size && var_type && var_weight && acc && loss_out, "combined_loss: null argument");
+    CODAE_REQUIRE(B > 0 && io > 0 && n_var > 0, "combined_loss: empty problem");
+    hipStream_t s = (hipStream_t)stream;
+    CODAE_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)n_var * sizeof(double), s));
+    const int grid = grid_for((int64_t)B * n_var);
+    hipLaunchKernelGGL(combined_reduce_kernel, dim3(grid), dim3(NT), 0, s, x, y, B, io, n_var, var_pos, var_size, var_type, acc);
+    CODAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(combined_grad_kernel, dim3(grid), dim3(NT), 0, s, x, y, B, io, n_var, var_pos, var_size, var_type,
+                       var_weight, acc, dy, loss_out);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+int codae_combined_loss_full(const float* x, const float* y, int32_t B, int32_t io, int32_t n_var, const int32_t* var_pos,
+                             const int32_t* var_size, const int32_t* var_type, float* out, void* stream) {
+    CODAE_REQUIRE(x && y && var_pos && var_size && var_type && out && B > 0 && io > 0 && n_var > 0, "combined_full: bad argument");
+    hipLaunchKernelGGL(combined_full_kernel, dim3(grid_for((int64_t)B * n_var)), dim3(NT), 0, (hipStream_t)stream, x, y, B, io,
+                       n_var, var_pos, var_size, var_type, out);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+int codae_row_norms(const float* m, int64_t rows, int32_t E, float* out, void* stream) {
+    CODAE_REQUIRE(m && out && rows > 0 && E > 0, "row_norms: bad argument");
+    int64_t g = (rows + 3) / 4;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(row_norm_kernel, dim3((unsigned)g), dim3(NT), 0, (hipStream_t)stream, m, rows, E, out);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+int codae_ranking_loss(const float* pred, const float* fmask, const int32_t* idx, int32_t B, int32_t io, int32_t n_slots,
+                       int32_t E, const float* inventory, const float* inventory_norm, int64_t n_obs, const int32_t* val_idx,
+                       int32_t n_val, double* out, void* stream) {
+    CODAE_REQUIRE(pred && fmask && idx && inventory && inventory_norm && val_idx && out, "ranking_loss: null argument");
+    CODAE_REQUIRE(B > 0 && n_slots > 0 && E > 0 && io == n_slots * E && n_val > 1 && n_obs > 0, "ranking_loss: bad sizes");
+    CODAE_REQUIRE((size_t)E * sizeof(float) <= 64 * 1024, "ranking_loss: embedding size %d too large for LDS staging", E);
+    hipLaunchKernelGGL(ranking_kernel, dim3(B), dim3(NT), (size_t)E * sizeof(float), (hipStream_t)stream, pred, fmask, idx, io,
+                       n_slots, E, inventory, inventory_norm, n_obs, val_idx, n_val, out);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+}  // extern "C"

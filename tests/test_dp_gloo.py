@@ -76,6 +76,8 @@ def test_two_ranks_match_single_process(tmp_path, n_buckets):
     assert np.array_equal(p0, p1), "replicas diverged"
     assert np.allclose(p0, ref.params.numpy(), rtol=1e-4, atol=1e-6)
     assert abs(float(np.load(tmp_path / "sq_0.npy")[0]) - ref.sq) < 1e-3 * ref.sq
-    assert default_buckets(10, 4) == [(8, 10), (5, 8), (2, 5), (0, 2)]
+    assert default_buckets(10, 4) == [(6, 10), (3, 6), (1, 3), (0, 1)]
     assert default_buckets(3, 8) == [(2, 3), (1, 2), (0, 1)]
+    assert default_buckets(6, 4) == [(4, 6), (2, 4), (1, 2), (0, 1)]
+    assert default_buckets(1, 4) == [(0, 1)]
     assert sorted(sum([list(range(a, b)) for a, b in default_buckets(10, 3)], [])) == list(range(10))

@@ -269,3 +269,48 @@ def test_mse_loss_dense(hip):
     assert abs(float(sc[hip.S_SQ_FULL]) - (d ** 2).sum()) < 1e-3
     assert abs(float(sc[hip.S_SQ_PARTIAL]) - ((1 - fm) * d ** 2).sum()) < 1e-3
     assert abs(float(sc[hip.S_LAST_LOSS]) - (d ** 2).mean()) < 1e-6
+
+
+def test_combined_criterion_kernels_match_oracle():
+    """CombinedCriterion on device tensors (codae_combined_loss_fwd_bwd / _full) vs the oracle:
+    loss, gradient (incl. the 1/(B s rmse) factor and softmax - onehot), monitor matrix."""
+    from golden_util import Golden, close
+    from codae.tool import CombinedCriterion
+    from oracle import dae_oracle as O
+    g = Golden("abalone_k2")
+    m = g.meta
+    arch = m["arch"]
+    rng = np.random.default_rng(8)
+    for B in (1, 37, 300):
+        x = g["data"][:B]
+        y = rng.standard_normal((B, 11)).astype(np.float32)
+        xt = torch.tensor(x, device=dev()); yt = torch.tensor(y, device=dev(), requires_grad=True)
+        crit = CombinedCriterion(arch, 2, dev(), torch.tensor(g["type_mask"]), weight=m["weight"], reduction="mean")
+        loss = crit(x=xt, y=yt)
+        (loss * 3.0).backward()
+        assert close(float(loss), O.combined_mean(arch, m["weight"], x, y))
+        assert close(yt.grad.cpu().numpy(), 3.0 * O.combined_mean_grad_y(arch, m["weight"], x, y), atol=1e-7)
+        mon = CombinedCriterion(arch, 2, dev(), torch.tensor(g["type_mask"]), reduction="none")
+        full = mon(xt, yt.detach(), as_numpy=True)
+        assert isinstance(full, np.ndarray) and close(full, O.combined_full(arch, x, y))
+
+
+def test_ranking_loss_kernel_matches_oracle():
+    from golden_util import Golden
+    from codae.tool import RankingLoss
+    from oracle import dae_oracle as O
+    ge = Golden("embedding_square")
+
+    class DS:
+        nb_predictor, nb_used_category, embedding_size = 48, 3, 16
+        data_per_category = {c: torch.tensor(ge["data_per_category"][c]) for c in range(3)}
+    val = [int(v) for v in ge["validation_indices"]]
+    rl = RankingLoss(DS(), val, device=dev())
+    rng = np.random.default_rng(4)
+    for call in (6, 7):
+        idx, run = ge.calls()[call]
+        _, fm = O.get_masks(ge["binary_masks"], ge["nb_missing_per_run"], ge["mask_to_use"], 1, idx, run)
+        pred = rng.standard_normal((len(idx), 48)).astype(np.float32)
+        got = rl.get(torch.tensor(pred, device=dev()), torch.tensor(fm, device=dev()), tuple(int(i) for i in idx))
+        ref = O.ranking_loss(pred, fm, idx, list(ge["data_per_category"]), 16, val)
+        assert abs(got - ref) <= 1e-3 * abs(ref) + 2.0 / (len(val) - 1), (got, ref)   # a near-tie may flip one comparison
