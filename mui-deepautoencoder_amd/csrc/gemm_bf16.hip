@@ -498,7 +498,10 @@ int gemm_bf16_tile_big(int M, int N, int split_k, bool k_strided = false) {
     const int64_t big = (int64_t)((M + 255) / 256) * ((N + 191) / 192) * split_k;
     // measured (tools/bench_gemm.py, 8192 x 1536 x 1536): forward 38 us with 256x192/8 waves vs 41 with
     // two 128x192 workgroups per CU; dgrad 51 vs 47; wgrad 60 vs 56
-    return big >= 160 ? (k_strided ? 4 : 1) : 0;
+    // ... but inside a dependent chain of layers (tools/bench_chain.py: inputs not cache-hot) the two-workgroup
+    // tile wins for the forward as well: 41-44 us per layer vs 44-48
+    (void)k_strided;
+    return big >= 160 ? 4 : 0;
 }
 
 int gemm_bf16(const GemmBf16& g, hipStream_t s) {
