@@ -91,6 +91,7 @@ enum {
     CODAE_S_GRAD_SQ = 2,     /* sum g^2 of the last codae_step_update (pre-clip)             */
     CODAE_S_LAST_LOSS = 3,   /* mean MSE of the last step (train_dae_on_embedding.py:206)    */
     CODAE_S_STEP_SQ = 4,     /* scratch: sum (x-y)^2 of the current step                     */
+    CODAE_S_CLIP_COEF = 5,   /* two slots (5, 6; step parity): clip coefficient of the last update        */
     CODAE_S_GRAD_SQ_SLOTS = 8, /* 64 partial sums of g^2: same-address atomics serialise (~12 ns each), so
                                   reduction kernels scatter over these slots; sum g^2 = GRAD_SQ + sum(slots) */
     CODAE_S_N_SLOTS = 64,
@@ -159,6 +160,10 @@ int codae_step_backward(codae_handle h, const codae_buffers* bufs, int32_t B, in
                         int32_t layer_hi, void* stream);
 /* global grad norm -> clip -> Adam -> bf16 shadow refresh (:212-215) */
 int codae_step_update(codae_handle h, const codae_buffers* bufs, const codae_hyper* hyper, void* stream);
+/* Make `stream` wait for everything the engine still has in flight on its own streams (the per-layer Adam
+ * kernels of the last update run beside the next forward).  Call before reading parameters, Adam state or
+ * gradients from another stream / the host. */
+int codae_join(codae_handle h, void* stream);
 /* all three, single GPU */
 int codae_train_step(codae_handle h, const codae_buffers* bufs, const codae_batch* batch,
                      const codae_hyper* hyper, void* stream);

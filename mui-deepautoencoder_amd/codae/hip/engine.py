@@ -49,7 +49,7 @@ class DaeEngine:
         self.n_param = int(sz.n_param)
         with torch.cuda.device(device):
             f32 = dict(dtype=torch.float32, device=device)
-            self.params = torch.zeros(self.n_param, **f32)
+            self._params = torch.zeros(self.n_param, **f32)
             self.grads = torch.zeros(self.n_param, **f32)
             self.adam_m = torch.zeros(self.n_param, **f32) if with_optimizer_state else None
             self.adam_v = torch.zeros(self.n_param, **f32) if with_optimizer_state else None
@@ -60,7 +60,7 @@ class DaeEngine:
             self.slabs = (torch.zeros(int(sz.slab_bytes), dtype=torch.uint8, device=device)
                           if sz.slab_bytes > 0 else None)
             self.scalars = torch.zeros(S_COUNT, dtype=torch.float64, device=device)
-        self.bufs = Buffers(ptr(self.params), ptr(self.grads), ptr(self.adam_m), ptr(self.adam_v), ptr(self.shadow),
+        self.bufs = Buffers(ptr(self._params), ptr(self.grads), ptr(self.adam_m), ptr(self.adam_v), ptr(self.shadow),
                             ptr(self.acts), ptr(self.dacts), ptr(self.slabs), ptr(self.scalars))
         self.w_off, self.b_off = [], []
         for l in range(self.L):
@@ -81,14 +81,26 @@ class DaeEngine:
             self._h = None
 
     # ---- views into the flat vectors --------------------------------------------------
+    def join(self):
+        """The last update's per-layer Adam kernels may still run on the engine's side stream: make the
+        current stream wait for them (call before reading parameters / Adam state / gradients)."""
+        with torch.cuda.device(self.device):
+            check(self._lib.codae_join(self._h, current_stream()))
+
+    @property
+    def params(self):
+        self.join()
+        return self._params
+
     def _view(self, flat, l, bias):
+        self.join()
         k, n, _ = self.schedule[l]
         if bias:
             return flat[self.b_off[l]:self.b_off[l] + n]
         return flat[self.w_off[l]:self.w_off[l] + n * k].view(n, k)
 
-    def weight(self, l): return self._view(self.params, l, False)
-    def bias(self, l): return self._view(self.params, l, True)
+    def weight(self, l): return self._view(self._params, l, False)
+    def bias(self, l): return self._view(self._params, l, True)
     def weight_grad(self, l): return self._view(self.grads, l, False)
     def bias_grad(self, l): return self._view(self.grads, l, True)
 

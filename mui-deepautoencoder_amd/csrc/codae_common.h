@@ -119,8 +119,10 @@ int launch_mse_loss(const codae_batch* b, const float* y, void* dy, int dy_bf16,
 int launch_mse_dense(const float* x, const float* y, const float* fmask, float* dy, int64_t n, float inv_n,
                      double* scalars, hipStream_t s);
 int launch_sumsq(const float* g, int64_t n, double* out, hipStream_t s);
+// coef_in != null: use that precomputed clip coefficient instead of folding grad_sq + slots
 int launch_clip_adam(float* p, float* g, float* m, float* v, int64_t n, const codae_hyper* hp,
-                     const double* grad_sq, bf16_t* shadow, const int64_t* shadow_map, hipStream_t s);
+                     const double* grad_sq, bf16_t* shadow, const double* coef_in, hipStream_t s);
+int launch_clip_coef(const double* grad_sq, float max_norm, double* coef_out, hipStream_t s);
 int launch_reduce_slabs(const float* slabs, int n_slabs, int64_t slab_stride, float* out, int64_t n, double* sumsq,
                         hipStream_t s);
 int launch_finish_loss(double* scalars, double inv_n, hipStream_t s);

@@ -283,12 +283,25 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
     p = p - c.lr_over_bc1 * (m / denom);
 }
 
+// coef_out = min(1, max_norm / (sqrt(sum g^2) + 1e-6)), sum g^2 = scalars[GRAD_SQ] + its slots
+__global__ void clip_coef_kernel(const double* __restrict__ grad_sq, float max_norm, double* __restrict__ coef_out) {
+    double v = grad_sq[(CODAE_S_GRAD_SQ_SLOTS - CODAE_S_GRAD_SQ) + threadIdx.x];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (threadIdx.x == 0) {
+        const float total = sqrtf((float)(v + grad_sq[0]));
+        *coef_out = (double)fminf(1.f, max_norm / (total + 1e-6f));
+    }
+}
+
 __global__ __launch_bounds__(NT) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                        float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                        AdamConst c, const double* __restrict__ grad_sq,
-                                                       bf16_t* __restrict__ shadow) {
+                                                       bf16_t* __restrict__ shadow, const double* __restrict__ coef_in) {
     float coef = 1.f;
-    if (c.max_norm > 0.f) {
+    if (coef_in != nullptr) {
+        coef = (float)(*coef_in);
+    } else if (c.max_norm > 0.f) {
         // sum g^2 = scalars[GRAD_SQ] + its 64 partial slots (one wave adds them up, LDS broadcasts)
         __shared__ double total_sq;
         if (threadIdx.x < 64) {
@@ -463,12 +476,19 @@ int launch_sumsq(const float* g, int64_t n, double* out, hipStream_t s) {
     return CODAE_OK;
 }
 
+int launch_clip_coef(const double* grad_sq, float max_norm, double* coef_out, hipStream_t s) {
+    CODAE_REQUIRE(grad_sq && coef_out, "clip_coef: null argument");
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, s, grad_sq, max_norm, coef_out);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
 int launch_clip_adam(float* p, float* g, float* m, float* v, int64_t n, const codae_hyper* hp,
-                     const double* grad_sq, bf16_t* shadow, const int64_t*, hipStream_t s) {
+                     const double* grad_sq, bf16_t* shadow, const double* coef_in, hipStream_t s) {
     CODAE_REQUIRE(p && g && m && v && hp && n > 0, "clip_adam: bad args");
     CODAE_REQUIRE(a16(p) && a16(g) && a16(m) && a16(v), "clip_adam: buffers must be 16-byte aligned");
     CODAE_REQUIRE(hp->step >= 1, "clip_adam: step must be >= 1");
-    CODAE_REQUIRE(hp->max_grad_norm <= 0.f || grad_sq, "clip_adam: clipping needs the grad_sq scalar");
+    CODAE_REQUIRE(hp->max_grad_norm <= 0.f || grad_sq || coef_in, "clip_adam: clipping needs the grad_sq scalar");
     AdamConst c;
     const double bc1 = 1.0 - pow((double)hp->beta1, (double)hp->step);
     const double bc2 = 1.0 - pow((double)hp->beta2, (double)hp->step);
@@ -476,7 +496,7 @@ int launch_clip_adam(float* p, float* g, float* m, float* v, int64_t n, const co
     c.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     c.beta1 = hp->beta1; c.beta2 = hp->beta2; c.eps = hp->eps; c.wd = hp->weight_decay;
     c.max_norm = hp->max_grad_norm;
-    hipLaunchKernelGGL(clip_adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, s, p, g, m, v, n, c, grad_sq, shadow);
+    hipLaunchKernelGGL(clip_adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, s, p, g, m, v, n, c, grad_sq, shadow, coef_in);
     CODAE_LAUNCH_CHECK();
     return CODAE_OK;
 }

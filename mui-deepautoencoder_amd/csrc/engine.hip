@@ -44,6 +44,10 @@ struct codae_engine {
     mutable hipStream_t side = nullptr, side2 = nullptr;   // side2: the HBM-bound slab reduces
     mutable hipEvent_t ev_ready = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_w[3] = {nullptr, nullptr, nullptr};
     mutable hipEvent_t ev_g[2] = {nullptr, nullptr}, ev_r[2] = {nullptr, nullptr};   // per slab buffer: GEMM done / reduce done
+    // deferred Adam: layer l's parameters are updated on `side` beside the NEXT forward; forward layer l waits ev_adam[l]
+    mutable hipEvent_t ev_adam[64] = {};
+    mutable bool adam_pending[64] = {};
+    mutable hipEvent_t ev_norm = nullptr;
     // single-GPU fused step: the slab reduce of every layer also accumulates sum g^2 (clip_grad_norm_)
     mutable bool norm_in_backward = false;
     mutable bool prof_on = false;
@@ -114,10 +118,30 @@ int check_common(codae_handle h, const codae_buffers* b, int B) {
     return CODAE_OK;
 }
 
+// the parameters of layer l may still be under the previous update's per-layer Adam kernel on the side stream
+int wait_layer_params(const codae_engine* e, int l, hipStream_t s) {
+    if (e->adam_pending[l]) {
+        CODAE_HIP_CHECK(hipStreamWaitEvent(s, e->ev_adam[l], 0));
+        e->adam_pending[l] = false;
+    }
+    return CODAE_OK;
+}
+int wait_all_params(const codae_engine* e, hipStream_t s) {
+    for (int l = 0; l < e->L; ++l) {
+        int rc = wait_layer_params(e, l, s);
+        if (rc) return rc;
+    }
+    return CODAE_OK;
+}
+
 // y = act(x W^T + b) for layer l
 int run_linear(const codae_engine* e, const codae_buffers* b, int l, const void* x, void* y, bool y_f32, int rows,
                hipStream_t s) {
     const int N = e->out[l], K = e->in[l];
+    {
+        int rcw = wait_layer_params(e, l, s);
+        if (rcw) return rcw;
+    }
     ProfScope prof(e, CODAE_K_GEMM_FWD, s);
     if (e->prec == CODAE_PREC_BF16) {
         GemmBf16 g{};
@@ -256,6 +280,8 @@ int ensure_side_stream(const codae_engine* h) {
     CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
     CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     for (int i = 0; i < 3; ++i) CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_w[i], hipEventDisableTiming));
+    CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_norm, hipEventDisableTiming));
+    for (int l = 0; l < h->L; ++l) CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_adam[l], hipEventDisableTiming));
     return CODAE_OK;
 }
 
@@ -397,6 +423,8 @@ int codae_destroy(codae_handle h) {
         (void)hipEventDestroy(h->ev_ready); (void)hipEventDestroy(h->ev_join);
         for (int i = 0; i < 3; ++i) (void)hipEventDestroy(h->ev_w[i]);
         (void)hipStreamSynchronize(h->side2);
+        (void)hipEventDestroy(h->ev_norm);
+        for (int l = 0; l < h->L; ++l) (void)hipEventDestroy(h->ev_adam[l]);
         (void)hipEventDestroy(h->ev_join2);
         for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(h->ev_g[i]); (void)hipEventDestroy(h->ev_r[i]); }
         (void)hipStreamDestroy(h->side); (void)hipStreamDestroy(h->side2);
@@ -453,6 +481,10 @@ int codae_param_offsets(codae_handle h, int32_t layer, int64_t* w_off, int64_t* 
 
 int codae_sync_shadows(codae_handle h, const codae_buffers* b, void* stream) {
     CODAE_REQUIRE(h && b && b->params, "codae_sync_shadows: null argument");
+    {
+        int rcw = wait_all_params(h, (hipStream_t)stream);
+        if (rcw) return rcw;
+    }
     if (h->prec != CODAE_PREC_BF16) return CODAE_OK;
     CODAE_REQUIRE(b->shadow_w, "codae_sync_shadows: shadow_w missing");
     return launch_cast_bf16(b->params, reinterpret_cast<bf16_t*>(b->shadow_w), h->n_param, (hipStream_t)stream);
@@ -494,6 +526,8 @@ int codae_backward(codae_handle h, const codae_buffers* b, const float* dy, floa
     CODAE_REQUIRE(dy && b->grads && b->dacts, "codae_backward: null dy / grads / dacts");
     CODAE_REQUIRE(layer_lo >= 0 && layer_lo < layer_hi && layer_hi <= h->L, "codae_backward: layer range [%d, %d)", layer_lo, layer_hi);
     hipStream_t s = (hipStream_t)stream;
+    rc = wait_all_params(h, s);
+    if (rc) return rc;
     const int rows = h->rows_for(B);
     const int top = layer_hi - 1;
     // bias gradients are accumulated with atomics by the producers of dA_l: clear this range
@@ -536,6 +570,8 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
     for (int l = 0; l < L; ++l) {
         const bool last = (l == L - 1);
         if (last && fuse_loss) {
+            rc = wait_layer_params(h, l, s);
+            if (rc) return rc;
             rc = zero_bias_grads(h, b, s);
             if (rc) return rc;
             const double n_glob = (double)(hyper->loss_scale_rows > 0.f ? hyper->loss_scale_rows : (float)B) * batch->io;
@@ -608,15 +644,62 @@ static int update_impl(codae_handle h, const codae_buffers* b, const codae_hyper
         }
         if (rc) return rc;
     }
-    ProfScope prof(h, CODAE_K_ADAM, s);
     bf16_t* shadow = h->prec == CODAE_PREC_BF16 ? reinterpret_cast<bf16_t*>(b->shadow_w) : nullptr;
     CODAE_REQUIRE(h->prec != CODAE_PREC_BF16 || shadow, "codae_step_update: shadow_w missing");
-    return launch_clip_adam(b->params, b->grads, b->adam_m, b->adam_v, h->n_param, hyper, b->scalars + CODAE_S_GRAD_SQ,
-                            shadow, nullptr, s);
+    // Measured at C3: hiding Adam under the next forward slows those GEMMs from 46.8 to 56.9 us each (HBM / L2
+    // contention) and the step from 1.76 to 1.84 ms, so this is opt-in (CODAE_DEFER_ADAM=1) only.
+    const bool deferred = h->L >= 2 && h->L <= 64 && getenv("CODAE_SINGLE_STREAM") == nullptr && getenv("CODAE_DEFER_ADAM") != nullptr;
+    if (!deferred) {
+        ProfScope prof(h, CODAE_K_ADAM, s);
+        return launch_clip_adam(b->params, b->grads, b->adam_m, b->adam_v, h->n_param, hyper, b->scalars + CODAE_S_GRAD_SQ,
+                                shadow, nullptr, s);
+    }
+    // Adam is a pure HBM pass (7 x 94 MB at C3) and the forward GEMMs that follow leave HBM mostly idle: update
+    // the bias block and layer 0 here, the other layers on the side stream in forward order; the next forward's
+    // layer l waits for event l only.  The clip coefficient is frozen first (the next step resets the norm
+    // scalars while late Adam kernels may still start), in a slot alternating with the step parity.
+    int rc = ensure_side_stream(h);
+    if (rc) return rc;
+    rc = wait_all_params(h, s);          // an update on top of a still-running update: order them
+    if (rc) return rc;
+    const double* coef = nullptr;
+    if (hyper->max_grad_norm > 0.f) {
+        double* slot = b->scalars + CODAE_S_CLIP_COEF + (hyper->step & 1);
+        rc = launch_clip_coef(b->scalars + CODAE_S_GRAD_SQ, hyper->max_grad_norm, slot, s);
+        if (rc) return rc;
+        coef = slot;
+    }
+    auto seg = [&](int64_t off, int64_t n, hipStream_t st) {
+        return launch_clip_adam(b->params + off, b->grads + off, b->adam_m + off, b->adam_v + off, n, hyper, nullptr,
+                                shadow ? shadow + off : nullptr, coef, st);
+    };
+    {
+        ProfScope prof(h, CODAE_K_ADAM, s);
+        rc = seg(h->bias_begin, h->n_param - h->bias_begin, s);
+        if (rc) return rc;
+        rc = seg(h->w_off[0], h->w_off[1] - h->w_off[0], s);
+        if (rc) return rc;
+    }
+    CODAE_HIP_CHECK(hipEventRecord(h->ev_norm, s));
+    CODAE_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_norm, 0));
+    for (int l = 1; l < h->L; ++l) {
+        const int64_t end = (l + 1 < h->L) ? h->w_off[l + 1] : h->bias_begin;
+        ProfScope prof(h, CODAE_K_ADAM, h->side);
+        rc = seg(h->w_off[l], end - h->w_off[l], h->side);
+        if (rc) return rc;
+        CODAE_HIP_CHECK(hipEventRecord(h->ev_adam[l], h->side));
+        h->adam_pending[l] = true;
+    }
+    return CODAE_OK;
 }
 
 int codae_step_update(codae_handle h, const codae_buffers* b, const codae_hyper* hyper, void* stream) {
     return update_impl(h, b, hyper, (hipStream_t)stream, false);
+}
+
+int codae_join(codae_handle h, void* stream) {
+    CODAE_REQUIRE(h != nullptr, "codae_join: null handle");
+    return wait_all_params(h, (hipStream_t)stream);
 }
 
 int codae_train_step(codae_handle h, const codae_buffers* b, const codae_batch* batch, const codae_hyper* hyper, void* stream) {
