@@ -165,7 +165,7 @@ int run_linear(const codae_engine* e, const codae_buffers* b, int l, const void*
 // dW_l = dA_l^T act[l].  bf16: split-K partial slabs, then a reduce.  With `rs` != null the reduce goes to that
 // stream and the slabs alternate between two buffers (slot), so the next layer's GEMM need not wait for it.
 int run_wgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, hipStream_t s, hipStream_t rs = nullptr,
-              int slot = 0, bool* slot_busy = nullptr) {
+              int slot = 0, bool* slot_busy = nullptr, bool defer_reduce = false, bool* deferred = nullptr) {
     const int N = e->out[l], K = e->in[l];
     float* dW = b->grads + e->w_off[l];
     if (e->prec == CODAE_PREC_BF16) {
@@ -190,10 +190,12 @@ int run_wgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, hi
             }
             if (rc) return rc;
             hipStream_t red = rs ? rs : s;
-            if (rs) {
-                CODAE_HIP_CHECK(hipEventRecord(e->ev_g[slot], s));
-                CODAE_HIP_CHECK(hipStreamWaitEvent(rs, e->ev_g[slot], 0));
+            if (rs) CODAE_HIP_CHECK(hipEventRecord(e->ev_g[slot], s));
+            if (rs && defer_reduce) {           // the caller issues run_slab_reduce(l, slot) later
+                *deferred = true;
+                return CODAE_OK;
             }
+            if (rs) CODAE_HIP_CHECK(hipStreamWaitEvent(rs, e->ev_g[slot], 0));
             {
                 ProfScope prof(e, CODAE_K_SLAB_REDUCE, red);
                 rc = launch_reduce_slabs(reinterpret_cast<const float*>(slab), S, (int64_t)N * K, dW, (int64_t)N * K,
@@ -217,6 +219,24 @@ int run_wgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, hi
     g.C = dW; g.ldc = K;
     g.M = N; g.N = K; g.K = rows;
     return gemm_f32(g, s);
+}
+
+// the slab reduce of layer l (slabs in buffer `slot`, GEMM completion = ev_g[slot]) on stream rs
+int run_slab_reduce(const codae_engine* e, const codae_buffers* b, int l, int rows, hipStream_t rs, int slot, bool* slot_busy) {
+    const int N = e->out[l], K = e->in[l];
+    const int S = e->split_k[l] <= rows / 64 ? e->split_k[l] : rows / 64;
+    const char* slab = reinterpret_cast<const char*>(b->slabs) + (int64_t)slot * e->slab_bytes;
+    CODAE_HIP_CHECK(hipStreamWaitEvent(rs, e->ev_g[slot], 0));
+    int rc;
+    {
+        ProfScope prof(e, CODAE_K_SLAB_REDUCE, rs);
+        rc = launch_reduce_slabs(reinterpret_cast<const float*>(slab), S, (int64_t)N * K, b->grads + e->w_off[l], (int64_t)N * K,
+                                 e->norm_in_backward ? b->scalars + CODAE_S_GRAD_SQ : nullptr, rs);
+    }
+    if (rc) return rc;
+    CODAE_HIP_CHECK(hipEventRecord(e->ev_r[slot], rs));
+    slot_busy[slot] = true;
+    return CODAE_OK;
 }
 
 // dA_{l-1} = (dA_l W_l) * [act[l] > 0]  (+ column sums -> db_{l-1});  l == 0 with dx: plain dX in fp32
@@ -298,20 +318,31 @@ int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi
                    hipStream_t s) {
     const int rows = h->rows_for(B);
     const bool dual = getenv("CODAE_SINGLE_STREAM") == nullptr;
-    const bool reduce_stream = getenv("CODAE_REDUCE_STREAM") != nullptr;
+    const bool reduce_stream = false;
     if (dual) {
         int rc = ensure_side_stream(h);
         if (rc) return rc;
     }
     bool w_pending[3] = {false, false, false};
     bool slot_busy[2] = {false, false};
+    // Where the HBM-bound slab reduces go: behind their GEMM on the side stream (default).  Measured alternatives:
+    // CODAE_REDUCE_STREAM=main issues them on `s` one layer late (two alternating slab buffers) - no difference
+    // (1.83 vs 1.82 ms: the two streams share the same CUs, so the sum of work decides, not the stream balance);
+    // =third uses a third stream - slower (1.84 ms).
+    const char* rmode = getenv("CODAE_REDUCE_STREAM");
+    const bool reduce_on_main = rmode != nullptr && rmode[0] == 'm';
+    int lag_layer = -1;          // layer whose reduce is still to be issued on s
     for (int l = hi - 1; l >= lo; --l) {
         int rc;
+        bool was_deferred = false;
         if (dual) {
             CODAE_HIP_CHECK(hipEventRecord(h->ev_ready, s));                // dA_l (and act[l]) are complete on s
             CODAE_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_ready, 0));
-            // (a third stream for the slab reduces measured slower than keeping them behind their GEMM: 1.84 vs 1.82 ms)
-            rc = run_wgrad(h, b, l, rows, h->side, reduce_stream ? h->side2 : nullptr, l & 1, slot_busy);
+            if (reduce_on_main)
+                rc = run_wgrad(h, b, l, rows, h->side, s, l & 1, slot_busy, true, &was_deferred);
+            else
+                rc = run_wgrad(h, b, l, rows, h->side, (reduce_stream || (rmode && rmode[0] == 't')) ? h->side2 : nullptr,
+                               l & 1, slot_busy);
             if (rc) return rc;
             CODAE_HIP_CHECK(hipEventRecord(h->ev_w[l % 3], h->side));
             w_pending[l % 3] = true;
@@ -330,6 +361,18 @@ int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi
             rc = chain ? run_dgrad(h, b, l, rows, nullptr, s) : run_dgrad(h, b, l, B, dx, s);
             if (rc) return rc;
         }
+        if (dual && reduce_on_main) {
+            if (lag_layer >= 0) {              // reduce of the previous layer, now that this layer's dgrad is queued
+                rc = run_slab_reduce(h, b, lag_layer, rows, s, lag_layer & 1, slot_busy);
+                if (rc) return rc;
+                lag_layer = -1;
+            }
+            if (was_deferred) lag_layer = l;
+        }
+    }
+    if (dual && reduce_on_main && lag_layer >= 0) {
+        int rc = run_slab_reduce(h, b, lag_layer, rows, s, lag_layer & 1, slot_busy);
+        if (rc) return rc;
     }
     if (dual) {
         CODAE_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
