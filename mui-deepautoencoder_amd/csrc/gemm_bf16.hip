@@ -500,8 +500,10 @@ int gemm_bf16_tile_big(int M, int N, int split_k, bool k_strided = false) {
     // two 128x192 workgroups per CU; dgrad 51 vs 47; wgrad 60 vs 56
     // ... but inside a dependent chain of layers (tools/bench_chain.py: inputs not cache-hot) the two-workgroup
     // tile wins for the forward as well: 41-44 us per layer vs 44-48
-    (void)k_strided;
-    return big >= 160 ? 4 : 0;
+    // and the 8-wave phase-pipelined kernel wins the forward form (KC x KC): 39.5-41 us per layer in the chain vs
+    // 42-46; its k-strided forms are slower (dgrad 57 vs 47 us, wgrad 79 vs 56), so those stay on the 128x192 tile
+    if (big < 160) return 0;
+    return k_strided ? 4 : 3;
 }
 
 int gemm_bf16(const GemmBf16& g, hipStream_t s) {
@@ -532,9 +534,9 @@ int gemm_bf16(const GemmBf16& g, hipStream_t s) {
         if (t) return launch_cfg<256, 192, 4, 2>(g, s);
         return launch_cfg<128, 128, 2, 2>(g, s);
     }
-    switch (gemm_bf16_tile_big(g.M, g.N, g.split_k, g.b_mode == OP_KS)) {
+    switch (gemm_bf16_tile_big(g.M, g.N, g.split_k, g.b_mode == OP_KS || g.c_f32)) {
         case 2: return gemm_bf16_pipe(g, 0, s);               // 256 x 192, 4 waves, phase-pipelined
-        case 3: return gemm_bf16_pipe(g, 1, s);               // 256 x 256, 8 waves, phase-pipelined
+        case 3: return gemm_bf16_pipe(g, 1, s);               // 256 x 192, 8 waves, phase-pipelined (forward default)
         case 1: return launch_cfg<256, 192, 4, 2>(g, s);      // 256 x 192, 8 waves, one barrier per K-tile
         case 4: return launch_cfg<128, 192, 2, 2>(g, s);      // 128 x 192, 4 waves, 80 KiB LDS: two workgroups per CU
         default: return launch_cfg<128, 128, 2, 2>(g, s);

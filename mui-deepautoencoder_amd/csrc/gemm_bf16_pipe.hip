@@ -78,12 +78,13 @@ __device__ __forceinline__ void interleave() {
 }
 
 // ---- half-tile images ------------------------------------------------------------------------
-// A half-tile holds, for every wave row (or column) of extent S, the h-th half (S/2) of it, packed:
-// local index l in [0, RH) <-> tile index (l / (S/2)) * S + h * (S/2) + l % (S/2).
+// Half-tile h is the contiguous range [h * RH, (h+1) * RH) of the tile's rows (columns); inside it wave row
+// (column) w owns [w * S/2, (w+1) * S/2).  So a wave's two halves are RH apart in the output, and a k-strided
+// half image fetches ONE contiguous 2*RH-byte segment per k-row (interleaving the waves' halves instead fetched
+// two half-used segments and cost 20-35 % on the dgrad / wgrad forms).
 template <int S>
-__device__ __forceinline__ int half_to_tile(int l, int h) {
-    constexpr int H = S / 2;
-    return (l / H) * S + h * H + (l % H);
+__device__ __forceinline__ int half_to_tile(int l, int h, int RH) {
+    return h * RH + l;
 }
 
 // KS image of a half: [64 k-rows][RH columns], 32-B blocks swizzled per k-row so that the 8 rows
@@ -123,7 +124,7 @@ __device__ __forceinline__ void stage_half(lds_char* img, const bf16_t* __restri
         if constexpr (MODE == OP_KC) {
             const int lr = j * 8 + (lane >> 3);
             const int c = (lane & 7) ^ ((lr >> 1) & 7);
-            int grow = r0 + half_to_tile<S>(lr, h);
+            int grow = r0 + half_to_tile<S>(lr, h, RH);
             grow = grow < rmax ? grow : rmax - 1;
             glds16(P + (int64_t)grow * ld + k0 + c * 8, img + j * 1024);
         } else {
@@ -132,7 +133,7 @@ __device__ __forceinline__ void stage_half(lds_char* img, const bf16_t* __restri
             const int kr = q / CPR;
             const int cp = q - kr * CPR;
             const int lc = (ks_from_lds_block<RH>(cp >> 1, kr) * 2 + (cp & 1)) * 8;
-            int col = r0 + half_to_tile<S>(lc, h);
+            int col = r0 + half_to_tile<S>(lc, h, RH);
             col = col + 8 <= rmax ? col : rmax - 8;
             glds16(P + (int64_t)(k0 + kr) * ld + col, img + j * 1024);
         }
@@ -321,75 +322,108 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
 
     // ---- epilogue: lane holds C[i][j .. j+3] of each 16 x 16 tile (swapped MFMA operands)
     const int li = lane & 15, g4 = (lane >> 4) * 4;
+    phase_barrier();          // every wave is past its last fragment read and every DMA has landed: LDS is free
+    if constexpr (!C_F32 && !dbg_nostore) {
+        // bf16 output through LDS, whole rows, 16 B per lane (see gemm_bf16.hip); mask + bias-grad sums ride along
+        constexpr int NT = 64 * NW;
+        constexpr int PITCH = BN * 2 + 16;
+        static_assert(BM * PITCH <= 2 * BUF, "output tile must fit in the staging buffers");
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int nt = 0; nt < TNH; ++nt) {
+                const int jl = nh * BHR + wc * (SN / 2) + 16 * nt + g4;
+                float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (g.bias != nullptr && j0 + jl < g.N) bj = *reinterpret_cast<const float4*>(g.bias + j0 + jl);
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                    for (int mt = 0; mt < TMH; ++mt) {
+                        const int il = mh * AHR + wr * (SM / 2) + 16 * mt + li;
+                        const f32x4 a = acc[mh][mt][nh][nt];
+                        float v0 = a[0] + bj.x, v1 = a[1] + bj.y, v2 = a[2] + bj.z, v3 = a[3] + bj.w;
+                        if (g.relu) {
+                            v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+                        }
+                        u32x2 o;
+                        o[0] = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
+                        o[1] = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
+                        *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(smem + il * PITCH + jl * 2) = o;
+                    }
+            }
+        __syncthreads();
+        constexpr int CH = BN / 8, RL = NT / CH;
+        const int c = threadIdx.x % CH, rl = threadIdx.x / CH;
+        const int j = j0 + c * 8;
+        float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (rl < RL && j < g.N) {
+            bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
+            for (int r = rl; r < BM; r += RL) {
+                const int i = i0 + r;
+                if (i >= g.M) break;
+                const u32x4 lv = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(smem + r * PITCH + c * 16);
+                uint4 v = make_uint4(lv[0], lv[1], lv[2], lv[3]);
+                if (g.relu_src != nullptr) {
+                    const uint4 h = *reinterpret_cast<const uint4*>(g.relu_src + (int64_t)i * g.ld_relu + j);
+                    auto keep = [](uint32_t val, uint32_t hh) -> uint32_t {
+                        const uint32_t lo = ((hh & 0x8000u) == 0 && (hh & 0x7fffu) != 0) ? 0x0000ffffu : 0u;
+                        const uint32_t hi = ((hh & 0x80000000u) == 0 && (hh & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
+                        return val & (lo | hi);
+                    };
+                    v.x = keep(v.x, h.x); v.y = keep(v.y, h.y); v.z = keep(v.z, h.z); v.w = keep(v.w, h.w);
+                }
+                *reinterpret_cast<uint4*>(Cb + (int64_t)i * g.ldc + j) = v;
+                if (g.colsum != nullptr) {
+                    cs[0] += bf16_to_f32((bf16_t)(v.x & 0xffff)); cs[1] += bf16_to_f32((bf16_t)(v.x >> 16));
+                    cs[2] += bf16_to_f32((bf16_t)(v.y & 0xffff)); cs[3] += bf16_to_f32((bf16_t)(v.y >> 16));
+                    cs[4] += bf16_to_f32((bf16_t)(v.z & 0xffff)); cs[5] += bf16_to_f32((bf16_t)(v.z >> 16));
+                    cs[6] += bf16_to_f32((bf16_t)(v.w & 0xffff)); cs[7] += bf16_to_f32((bf16_t)(v.w >> 16));
+                }
+            }
+        }
+        if (g.colsum != nullptr) {
+            __syncthreads();
+            float* red = reinterpret_cast<float*>(smem_raw);
+            static_assert(RL * BN * 4 <= 2 * BUF, "reduction scratch must fit");
+            if (rl < RL) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) red[rl * BN + c * 8 + k] = cs[k];
+            }
+            __syncthreads();
+            for (int col = threadIdx.x; col < BN; col += NT) {
+                float sum = 0.f;
+                for (int r = 0; r < RL; ++r) sum += red[r * BN + col];
+                if (j0 + col < g.N) atomicAdd(&g.colsum[j0 + col], sum);
+            }
+        }
+        return;
+    }
+    // fp32 output (split-K slabs / fp32 y): 16 B per lane straight from the accumulators
     char* Cbase = reinterpret_cast<char*>(g.C);
     if (g.split_k > 1) Cbase += (int64_t)z * g.M * g.ldc * sizeof(float);
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
         for (int nt = 0; nt < TNH; ++nt) {
-            const int j = j0 + wc * SN + nh * (SN / 2) + 16 * nt + g4;
+            const int j = j0 + nh * BHR + wc * (SN / 2) + 16 * nt + g4;
             const bool jok = j < g.N;
             float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
             if (g.bias != nullptr && jok) bj = *reinterpret_cast<const float4*>(g.bias + j);
-            float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f;
-            // ReLU masks of this column group: one batch of unconditional loads (addresses clamped into
-            // the matrix) so that they are all in flight together instead of one round trip per tile
-            uint2 hm[2][TMH];
-            if (g.relu_src != nullptr) {
-                const int jc = jok ? j : 0;
-#pragma unroll
-                for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-                    for (int mt = 0; mt < TMH; ++mt) {
-                        int ic = i0 + wr * SM + mh * (SM / 2) + 16 * mt + li;
-                        ic = ic < g.M ? ic : g.M - 1;
-                        hm[mh][mt] = *reinterpret_cast<const uint2*>(g.relu_src + (int64_t)ic * g.ld_relu + jc);
-                    }
-            } else {
-#pragma unroll
-                for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-                    for (int mt = 0; mt < TMH; ++mt) hm[mh][mt] = make_uint2(0x3f803f80u, 0x3f803f80u);   // 1.0: keep
-            }
 #pragma unroll
             for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
                 for (int mt = 0; mt < TMH; ++mt) {
-                    const int i = i0 + wr * SM + mh * (SM / 2) + 16 * mt + li;
+                    const int i = i0 + mh * AHR + wr * (SM / 2) + 16 * mt + li;
                     if (i < g.M && jok && !dbg_nostore) {
                         const f32x4 a = acc[mh][mt][nh][nt];
                         float v0 = a[0] + bj.x, v1 = a[1] + bj.y, v2 = a[2] + bj.z, v3 = a[3] + bj.w;
                         if (g.relu) {
                             v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
                         }
-                        const uint2 h = hm[mh][mt];
-                        // bf16 > 0  <=>  sign clear and magnitude non-zero
-                        v0 = ((h.x & 0x8000u) == 0 && (h.x & 0x7fffu) != 0) ? v0 : 0.f;
-                        v1 = ((h.x & 0x80000000u) == 0 && (h.x & 0x7fff0000u) != 0) ? v1 : 0.f;
-                        v2 = ((h.y & 0x8000u) == 0 && (h.y & 0x7fffu) != 0) ? v2 : 0.f;
-                        v3 = ((h.y & 0x80000000u) == 0 && (h.y & 0x7fff0000u) != 0) ? v3 : 0.f;
-                        if constexpr (C_F32) {
+                        if constexpr (C_F32)
                             *reinterpret_cast<float4*>(Cbase + ((int64_t)i * g.ldc + j) * 4) = make_float4(v0, v1, v2, v3);
-                        } else {
-                            uint2 o;
-                            o.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
-                            o.y = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
-                            *reinterpret_cast<uint2*>(Cbase + ((int64_t)i * g.ldc + j) * 2) = o;
-                        }
-                        cs0 += v0; cs1 += v1; cs2 += v2; cs3 += v3;
                     }
                 }
-            if (g.colsum != nullptr) {
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    cs0 += __shfl_xor(cs0, o); cs1 += __shfl_xor(cs1, o);
-                    cs2 += __shfl_xor(cs2, o); cs3 += __shfl_xor(cs3, o);
-                }
-                if (li == 0 && jok) {
-                    atomicAdd(&g.colsum[j + 0], cs0); atomicAdd(&g.colsum[j + 1], cs1);
-                    atomicAdd(&g.colsum[j + 2], cs2); atomicAdd(&g.colsum[j + 3], cs3);
-                }
-            }
         }
 }
 

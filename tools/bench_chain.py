@@ -39,10 +39,12 @@ def timeit(fn, n=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 
-for rnd in range(2):
-    for tile in ("b", "c"):
+tiles = sys.argv[1].split(",") if len(sys.argv) > 1 else ["b", "c", "q"]
+for rnd in range(3):
+    for tile in tiles:
         os.environ["CODAE_GEMM_TILE"] = tile
         print("tile %s  full batch, 1 stream : %7.1f us per 10 layers" % (tile, timeit(full)))
+if len(sys.argv) > 2:
+    for tile in tiles:
+        os.environ["CODAE_GEMM_TILE"] = tile
         print("tile %s  2 halves, 2 streams  : %7.1f us" % (tile, timeit(lambda: halves([(0, 4096), (4096, 4096)]))))
-        print("tile %s  5/3 split, 2 streams : %7.1f us" % (tile, timeit(lambda: halves([(0, 5120), (5120, 3072)]))))
-        print("tile %s  3 parts, 3 streams   : %7.1f us" % (tile, timeit(lambda: halves([(0, 2816), (2816, 2816), (5632, 2560)]))))
