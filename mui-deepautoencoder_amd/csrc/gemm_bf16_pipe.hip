@@ -111,32 +111,28 @@ __device__ __forceinline__ int ks_from_lds_block(int lds_block, int kr) {
     }
 }
 
-// LDS-DMA one half-tile (RH rows/cols x 64 k = RH/8 wave-instructions, RH/8/NW per wave).
+// Global source (at k = 0) of the 16 bytes lane `lane` of loader wave `w` places with its `it`-th LDS-DMA
+// instruction of half-tile h (instruction j = it * NW + w writes img + j * 1024 + lane * 16).  Everything here
+// is loop invariant: the K loop only adds tile * (64 elements | 64 rows) to these pointers.
 template <int MODE, int RH, int S, int NW>
-__device__ __forceinline__ void stage_half(lds_char* img, const bf16_t* __restrict__ P, int64_t ld, int r0, int rmax,
-                                           int k0, int h, int w, int lane) {
-    // NW here = number of LOADER waves of this half-tile (waves w >= NW do not call)
-    constexpr int NI = RH / 8 / NW;
-    static_assert(NI * NW * 8 == RH, "half-tile must split evenly over the loader waves");
-#pragma unroll
-    for (int it = 0; it < NI; ++it) {
-        const int j = it * NW + w;
-        if constexpr (MODE == OP_KC) {
-            const int lr = j * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ ((lr >> 1) & 7);
-            int grow = r0 + half_to_tile<S>(lr, h, RH);
-            grow = grow < rmax ? grow : rmax - 1;
-            glds16(P + (int64_t)grow * ld + k0 + c * 8, img + j * 1024);
-        } else {
-            constexpr int CPR = RH / 8;
-            const int q = j * 64 + lane;
-            const int kr = q / CPR;
-            const int cp = q - kr * CPR;
-            const int lc = (ks_from_lds_block<RH>(cp >> 1, kr) * 2 + (cp & 1)) * 8;
-            int col = r0 + half_to_tile<S>(lc, h, RH);
-            col = col + 8 <= rmax ? col : rmax - 8;
-            glds16(P + (int64_t)(k0 + kr) * ld + col, img + j * 1024);
-        }
+__device__ __forceinline__ const bf16_t* half_src(const bf16_t* __restrict__ P, int64_t ld, int r0, int rmax, int h, int it,
+                                                  int w, int lane) {
+    const int j = it * NW + w;
+    if constexpr (MODE == OP_KC) {
+        const int lr = j * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((lr >> 1) & 7);
+        int grow = r0 + half_to_tile<S>(lr, h, RH);
+        grow = grow < rmax ? grow : rmax - 1;
+        return P + (int64_t)grow * ld + c * 8;
+    } else {
+        constexpr int CPR = RH / 8;
+        const int q = j * 64 + lane;
+        const int kr = q / CPR;
+        const int cp = q - kr * CPR;
+        const int lc = (ks_from_lds_block<RH>(cp >> 1, kr) * 2 + (cp & 1)) * 8;
+        int col = r0 + half_to_tile<S>(lc, h, RH);
+        col = col + 8 <= rmax ? col : rmax - 8;
+        return P + (int64_t)kr * ld + col;
     }
 }
 
@@ -200,20 +196,38 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
     auto b_img = [&](int tile, int h) { return smem + (tile & 1) * BUF + 2 * AH + h * BH; };
     // timing-only ablations (compile-time; DBG = 0 in the shipped instantiations)
     constexpr bool dbg_noload = DBG & 1, dbg_nomma = DBG & 2, dbg_nostore = DBG & 4;
+    // per-lane LDS-DMA source pointers at k = 0 (loop invariant) and the per-K-tile advance
+    const bool b_loader = (NLB == NW) || (w < NLB);
+    const bf16_t* a_src[2][NA];
+    const bf16_t* b_src[2][NB];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int it = 0; it < NA; ++it) a_src[h][it] = half_src<A_MODE, AHR, SM, NW>(g.A, g.lda, i0, g.M, h, it, w, lane) + (A_MODE == OP_KC ? (int64_t)kt_begin * BK : (int64_t)kt_begin * BK * g.lda);
+#pragma unroll
+        for (int it = 0; it < NB; ++it) b_src[h][it] = half_src<B_MODE, BHR, SN, NLB>(g.B, g.ldb, j0, g.N, h, it, b_loader ? w : 0, lane) + (B_MODE == OP_KC ? (int64_t)kt_begin * BK : (int64_t)kt_begin * BK * g.ldb);
+    }
+    const int64_t a_step = A_MODE == OP_KC ? BK : (int64_t)BK * g.lda;
+    const int64_t b_step = B_MODE == OP_KC ? BK : (int64_t)BK * g.ldb;
     // Loads past the last K-tile are issued anyway, re-reading the last tile into the (dead) region
     // the schedule assigns: every phase stays one straight-line block the scheduler can interleave,
     // and the vmcnt arithmetic is exact to the end (cost: ~2 extra K-tiles of L2-hit DMA per workgroup).
     auto issue_a = [&](int tile, int h) {
         if constexpr (!dbg_noload) {
-            const int src = tile < nkt ? tile : nkt - 1;
-            stage_half<A_MODE, AHR, SM, NW>(a_img(tile, h), g.A, g.lda, i0, g.M, (kt_begin + src) * BK, h, w, lane);
+            const int64_t adv = (int64_t)(tile < nkt ? tile : nkt - 1) * a_step;
+            lds_char* img = a_img(tile, h);
+#pragma unroll
+            for (int it = 0; it < NA; ++it) glds16(a_src[h][it] + adv, img + (it * NW + w) * 1024);
         }
     };
     auto issue_b = [&](int tile, int h) {
         if constexpr (!dbg_noload) {
-            const int src = tile < nkt ? tile : nkt - 1;
-            if (NLB == NW || w < NLB)
-                stage_half<B_MODE, BHR, SN, NLB>(b_img(tile, h), g.B, g.ldb, j0, g.N, (kt_begin + src) * BK, h, w, lane);
+            if (b_loader) {
+                const int64_t adv = (int64_t)(tile < nkt ? tile : nkt - 1) * b_step;
+                lds_char* img = b_img(tile, h);
+#pragma unroll
+                for (int it = 0; it < NB; ++it) glds16(b_src[h][it] + adv, img + (it * NLB + w) * 1024);
+            }
         }
     };
 
