@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcodae_hip.so")
+# CODAE_HIP_LIB: load another build of the library (same-box A/B of kernel variants)
+LIB_PATH = os.environ.get("CODAE_HIP_LIB") or os.path.join(_HERE, "libcodae_hip.so")
 
 PREC_F32 = 0
 PREC_BF16 = 1
