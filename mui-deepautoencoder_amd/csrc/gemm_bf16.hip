@@ -11,9 +11,11 @@
 //
 // so no transposed copy of the weights or activations is ever written to HBM.
 //
-// Workgroup tile BM x BN x 64 with WM x WN waves: 256 x 192 with 8 waves (4 x 2, 64 x 96 per wave,
-// 112 KiB LDS, one workgroup per CU: 8192 x 1536 outputs = 32 x 8 = 256 tiles = one per CU) when
-// the problem fills the chip, else 128 x 128 with 4 waves (64 KiB LDS, two workgroups per CU).
+// Workgroup tile BM x BN x 64 with WM x WN waves.  Large problems: 128 x 192 with 4 waves and exactly
+// 80 KiB of LDS, so TWO workgroups with independent barriers share a CU (8192 x 1536 outputs = 512 tiles
+// = two per CU) - the default for the k-strided forms (dgrad, wgrad) and the fused-loss layer; the plain
+// forward form goes to the phase-pipelined kernel (gemm_bf16_pipe.hip).  Also built: 256 x 192 with 8
+// waves (one workgroup per CU) and, for small problems, 128 x 128 with 4 waves.
 // Both operand tiles are staged HBM -> LDS with global_load_lds_dwordx4 (LDS-DMA, 1 KiB per
 // wave-instruction, no VGPR round trip), double-buffered; the LDS image is lane-linear, so the
 // bank swizzle is applied to the per-lane SOURCE address and again on the read:
@@ -104,23 +106,6 @@ __device__ __forceinline__ void stage_tile(lds_char* tile, const bf16_t* __restr
     }
 }
 
-// The same tile through the second load path: global_load_dwordx4 into registers now, one lane-linear
-// ds_write_b128 per instruction later (the image is identical to the LDS-DMA one).  The LDS-DMA path
-// of a CU saturates near 70-76 GB/s; splitting the two operands over both paths halves its load.
-template <int MODE, int R, int NW>
-__device__ __forceinline__ void stage_tile_load(u32x4 (&regs)[R * 128 / 1024 / NW], const bf16_t* __restrict__ P, int64_t ld,
-                                                int r0, int rmax, int k0, int w, int lane) {
-#pragma unroll
-    for (int it = 0; it < R * 128 / 1024 / NW; ++it)
-        regs[it] = *reinterpret_cast<const u32x4*>(stage_src<MODE, R>(P, ld, r0, rmax, k0, it * NW + w, lane));
-}
-template <int R, int NW>
-__device__ __forceinline__ void stage_tile_write(lds_char* tile, const u32x4 (&regs)[R * 128 / 1024 / NW], int w, int lane) {
-#pragma unroll
-    for (int it = 0; it < R * 128 / 1024 / NW; ++it)
-        *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(tile + (it * NW + w) * 1024 + lane * 16) = regs[it];
-}
-
 // One 8-element MFMA fragment of 16-row/col tile `t`, k-step `s` (32 deep) of an operand tile.
 template <int MODE, int R>
 __device__ __forceinline__ bf16x8 read_frag(const lds_char* tile, int t, int s, int lane) {
@@ -143,7 +128,7 @@ __device__ __forceinline__ bf16x8 read_frag(const lds_char* tile, int t, int s, 
 }
 
 // Tile BM x BN x 64, WM x WN waves, each wave (BM/WM) x (BN/WN) = TM x TN MFMA tiles of 16 x 16.
-template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, bool C_F32, bool LOSS = false, bool B_REGS = false>
+template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, bool C_F32, bool LOSS = false>
 __global__ __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256 * ((2 * (BM + BN) * 128 <= 80 * 1024) ? 2 : 1))
 void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
     constexpr int NW = WM * WN;
@@ -177,15 +162,9 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
 #pragma unroll
         for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    u32x4 breg[BN * 128 / 1024 / NW];
     if (nkt > 0) {
         stage_tile<A_MODE, BM, NW>(smem, g.A, g.lda, i0, g.M, kt_begin * BK, w, lane);
-        if constexpr (B_REGS) {
-            stage_tile_load<B_MODE, BN, NW>(breg, g.B, g.ldb, j0, g.N, kt_begin * BK, w, lane);
-            stage_tile_write<BN, NW>(smem + A_BYTES, breg, w, lane);
-        } else {
-            stage_tile<B_MODE, BN, NW>(smem + A_BYTES, g.B, g.ldb, j0, g.N, kt_begin * BK, w, lane);
-        }
+        stage_tile<B_MODE, BN, NW>(smem + A_BYTES, g.B, g.ldb, j0, g.N, kt_begin * BK, w, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -195,8 +174,7 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
         if (kt + 1 < nkt) {
             const int k0 = (kt_begin + kt + 1) * BK;
             stage_tile<A_MODE, BM, NW>(nxt, g.A, g.lda, i0, g.M, k0, w, lane);
-            if constexpr (B_REGS) stage_tile_load<B_MODE, BN, NW>(breg, g.B, g.ldb, j0, g.N, k0, w, lane);
-            else stage_tile<B_MODE, BN, NW>(nxt + A_BYTES, g.B, g.ldb, j0, g.N, k0, w, lane);
+            stage_tile<B_MODE, BN, NW>(nxt + A_BYTES, g.B, g.ldb, j0, g.N, k0, w, lane);
         }
         // fragments of BOTH k-steps are requested up front: the MFMAs of k-step 0 start as soon as
         // their operands are back (counted lgkmcnt) while the reads of k-step 1 are still in flight
@@ -216,10 +194,6 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
                 for (int nt = 0; nt < TN; ++nt)
                     // swapped operands: D rows <-> output column (n), D cols <-> output row (m)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s][nt], af[s][mt], acc[mt][nt], 0, 0, 0);
-        if constexpr (B_REGS) {
-            // nxt's B image was last read one iteration ago (a barrier since): write it now
-            if (kt + 1 < nkt) stage_tile_write<BN, NW>(nxt + A_BYTES, breg, w, lane);
-        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
