@@ -82,6 +82,9 @@ typedef struct {
     void* dacts;        /* dact_bytes */
     void* slabs;        /* slab_bytes */
     double* scalars;    /* n_scalars doubles, see CODAE_S_* */
+    void* shadow_wt;    /* optional (BF16 mode): bf16 TRANSPOSED weights, per layer [in][out] at the same offsets as
+                           shadow_w; when present the data-gradient GEMM reads it k-contiguously (forward-form
+                           kernel) instead of reading W through transposed LDS reads; n_weight elements */
 } codae_buffers;
 
 /* indices into codae_buffers.scalars (device memory, accumulated across calls until zeroed) */
@@ -246,6 +249,9 @@ int codae_dgrad_bf16(const void* dy, const void* W, const void* relu_src, void* 
 int codae_wgrad_bf16(const void* dy, const void* x, float* dW, void* slabs, int64_t slab_bytes,
                      int32_t M, int32_t N, int32_t K, void* stream);
 int codae_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* dst[c][r] = src[r][c] on bf16 matrices (rows, cols multiples of 8): the kernel that refreshes codae_buffers.shadow_wt
+ * after each parameter update (W.t() in torch.nn.Linear's data gradient, embedding_denoising_autoencoder.py:137-151). */
+int codae_transpose_bf16(const void* src, void* dst, int32_t rows, int32_t cols, void* stream);
 
 #ifdef __cplusplus
 }

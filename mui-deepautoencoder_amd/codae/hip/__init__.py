@@ -39,7 +39,7 @@ class Sizes(C.Structure):
 class Buffers(C.Structure):
     _fields_ = [("params", C.c_void_p), ("grads", C.c_void_p), ("adam_m", C.c_void_p),
                 ("adam_v", C.c_void_p), ("shadow_w", C.c_void_p), ("acts", C.c_void_p),
-                ("dacts", C.c_void_p), ("slabs", C.c_void_p), ("scalars", C.c_void_p)]
+                ("dacts", C.c_void_p), ("slabs", C.c_void_p), ("scalars", C.c_void_p), ("shadow_wt", C.c_void_p)]
 
 
 class Batch(C.Structure):
@@ -90,6 +90,7 @@ PROTOTYPES = {
     "codae_dgrad_bf16": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
     "codae_wgrad_bf16": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P]),
     "codae_cast_f32_to_bf16": (C.c_int, [_P, _P, _I64, _P]),
+    "codae_transpose_bf16": (C.c_int, [_P, _P, _I32, _I32, _P]),
 }
 
 _lib = None

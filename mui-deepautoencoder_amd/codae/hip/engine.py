@@ -55,13 +55,16 @@ class DaeEngine:
             self.adam_v = torch.zeros(self.n_param, **f32) if with_optimizer_state else None
             self.shadow = (torch.zeros(int(sz.n_weight), dtype=torch.bfloat16, device=device)
                            if sz.n_weight > 0 else None)
+            # transposed bf16 weights [in][out] per layer: lets the data-gradient GEMM run in the forward form
+            self.shadow_t = (torch.zeros(int(sz.n_weight), dtype=torch.bfloat16, device=device)
+                             if sz.n_weight > 0 else None)
             self.acts = torch.zeros(max(int(sz.act_bytes), 16), dtype=torch.uint8, device=device)
             self.dacts = torch.zeros(max(int(sz.dact_bytes), 16), dtype=torch.uint8, device=device)
             self.slabs = (torch.zeros(int(sz.slab_bytes), dtype=torch.uint8, device=device)
                           if sz.slab_bytes > 0 else None)
             self.scalars = torch.zeros(S_COUNT, dtype=torch.float64, device=device)
         self.bufs = Buffers(ptr(self._params), ptr(self.grads), ptr(self.adam_m), ptr(self.adam_v), ptr(self.shadow),
-                            ptr(self.acts), ptr(self.dacts), ptr(self.slabs), ptr(self.scalars))
+                            ptr(self.acts), ptr(self.dacts), ptr(self.slabs), ptr(self.scalars), ptr(self.shadow_t))
         self.w_off, self.b_off = [], []
         for l in range(self.L):
             w, b, s = C.c_int64(), C.c_int64(), C.c_int64()

@@ -122,6 +122,9 @@ int launch_sumsq(const float* g, int64_t n, double* out, hipStream_t s);
 // coef_in != null: use that precomputed clip coefficient instead of folding grad_sq + slots
 int launch_clip_adam(float* p, float* g, float* m, float* v, int64_t n, const codae_hyper* hp,
                      const double* grad_sq, bf16_t* shadow, const double* coef_in, hipStream_t s);
+// dst[c][r] = src[r][c] for n bf16 matrices (element offsets off[i], shapes rows[i] x cols[i]) in one launch
+int launch_transpose_bf16(const bf16_t* src, bf16_t* dst, int n, const int64_t* off, const int* rows, const int* cols,
+                          hipStream_t s);
 int launch_clip_coef(const double* grad_sq, float max_norm, double* coef_out, hipStream_t s);
 int launch_reduce_slabs(const float* slabs, int n_slabs, int64_t slab_stride, float* out, int64_t n, double* sumsq,
                         hipStream_t s);

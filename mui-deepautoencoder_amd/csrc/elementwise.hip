@@ -379,6 +379,50 @@ __global__ __launch_bounds__(NT) void colsum_f32_kernel(const float* __restrict_
     }
 }
 
+// dst[c][r] = src[r][c] for up to 64 bf16 matrices in one launch (the transposed weight shadows);
+// 64 x 64 tiles through LDS, 16-byte global accesses on both sides
+struct TransposeJobs {
+    int n;
+    int64_t off[64];        // element offset of the matrix in src and dst
+    int rows[64], cols[64]; // src is [rows][cols]
+    int tile_begin[65];     // prefix sum of tiles per matrix
+};
+__global__ __launch_bounds__(NT) void transpose_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                            TransposeJobs jobs) {
+    __shared__ bf16_t tile[64][72];          // 72: rows stay 16-byte aligned, banks staggered
+    int m = 0;
+    while (m + 1 < jobs.n && (int)blockIdx.x >= jobs.tile_begin[m + 1]) ++m;
+    const int t = blockIdx.x - jobs.tile_begin[m];
+    const int R = jobs.rows[m], C = jobs.cols[m];
+    const int tiles_c = (C + 63) / 64;
+    const int r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+    const bf16_t* S = src + jobs.off[m];
+    bf16_t* D = dst + jobs.off[m];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int q = threadIdx.x + p * NT;      // 512 chunks of 8 elements
+        const int r = q >> 3, c8 = (q & 7) * 8;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (r0 + r < R && c0 + c8 < C) v = *reinterpret_cast<const uint4*>(S + (int64_t)(r0 + r) * C + c0 + c8);
+        *reinterpret_cast<uint4*>(&tile[r][c8]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int q = threadIdx.x + p * NT;
+        const int c = q >> 3, r8 = (q & 7) * 8;  // output row c (a source column), 8 source rows r8..r8+7
+        if (c0 + c < C && r0 + r8 < R) {
+            bf16_t e[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e[k] = tile[r8 + k][c];
+            uint4 v;
+            v.x = (uint32_t)e[0] | ((uint32_t)e[1] << 16); v.y = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
+            v.z = (uint32_t)e[4] | ((uint32_t)e[5] << 16); v.w = (uint32_t)e[6] | ((uint32_t)e[7] << 16);
+            *reinterpret_cast<uint4*>(D + (int64_t)(c0 + c) * R + r0 + r8) = v;
+        }
+    }
+}
+
 inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -504,6 +548,24 @@ int launch_clip_adam(float* p, float* g, float* m, float* v, int64_t n, const co
 int launch_colsum_f32(const float* src, int M, int N, float* out, hipStream_t s) {
     CODAE_REQUIRE(src && out && M > 0 && N > 0, "colsum: bad args");
     hipLaunchKernelGGL(colsum_f32_kernel, dim3((M + 63) / 64), dim3(NT), 0, s, src, M, N, out);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+int launch_transpose_bf16(const bf16_t* src, bf16_t* dst, int n, const int64_t* off, const int* rows, const int* cols,
+                          hipStream_t s) {
+    CODAE_REQUIRE(src && dst && n > 0 && n <= 64, "transpose: bad args");
+    TransposeJobs jobs;
+    jobs.n = n;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        CODAE_REQUIRE(rows[i] % 8 == 0 && cols[i] % 8 == 0, "transpose: matrix %d is %d x %d (need multiples of 8)", i, rows[i], cols[i]);
+        jobs.off[i] = off[i]; jobs.rows[i] = rows[i]; jobs.cols[i] = cols[i];
+        jobs.tile_begin[i] = total;
+        total += ((rows[i] + 63) / 64) * ((cols[i] + 63) / 64);
+    }
+    jobs.tile_begin[n] = total;
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(total), dim3(NT), 0, s, src, dst, jobs);
     CODAE_LAUNCH_CHECK();
     return CODAE_OK;
 }

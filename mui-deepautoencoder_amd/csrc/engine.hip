@@ -247,7 +247,12 @@ int run_dgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, fl
     if (e->prec == CODAE_PREC_BF16) {
         GemmBf16 g{};
         g.A = reinterpret_cast<const bf16_t*>(dact_ptr(e, b, l)); g.lda = N; g.a_mode = OP_KC;
-        g.B = reinterpret_cast<const bf16_t*>(b->shadow_w) + e->w_off[l]; g.ldb = K; g.b_mode = OP_KS;
+        if (b->shadow_wt != nullptr && l >= 1 && getenv("CODAE_NO_WT") == nullptr) {
+            // dx[m][k] = sum_n dy[m][n] Wt[k][n]: both operands k-contiguous -> the forward-form kernel
+            g.B = reinterpret_cast<const bf16_t*>(b->shadow_wt) + e->w_off[l]; g.ldb = N; g.b_mode = OP_KC;
+        } else {
+            g.B = reinterpret_cast<const bf16_t*>(b->shadow_w) + e->w_off[l]; g.ldb = K; g.b_mode = OP_KS;
+        }
         g.M = rows; g.N = K; g.K = N;
         g.ldc = K; g.split_k = 1;
         if (to_dx) {
@@ -272,6 +277,20 @@ int run_dgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, fl
         g.colsum = b->grads + e->b_off[l - 1];
     }
     return gemm_f32(g, s);
+}
+
+// Wt_l [in][out] <- W_l [out][in] (bf16) for every layer that has a data gradient (l >= 1)
+int refresh_transposed(const codae_engine* e, const codae_buffers* b, hipStream_t s, int l_lo = 1, int l_hi = -1) {
+    if (e->prec != CODAE_PREC_BF16 || b->shadow_wt == nullptr || e->L < 2) return CODAE_OK;
+    if (l_hi < 0) l_hi = e->L;
+    for (int base = l_lo; base < l_hi; base += 64) {             // the launch carries at most 64 matrices
+        int64_t off[64]; int rows[64], cols[64]; int n = 0;
+        for (int l = base; l < l_hi && n < 64; ++l) { off[n] = e->w_off[l]; rows[n] = e->out[l]; cols[n] = e->in[l]; ++n; }
+        int rc = launch_transpose_bf16(reinterpret_cast<const bf16_t*>(b->shadow_w), reinterpret_cast<bf16_t*>(b->shadow_wt),
+                                       n, off, rows, cols, s);
+        if (rc) return rc;
+    }
+    return CODAE_OK;
 }
 
 int zero_bias_grads(const codae_engine* e, const codae_buffers* b, hipStream_t s) {
@@ -530,7 +549,9 @@ int codae_sync_shadows(codae_handle h, const codae_buffers* b, void* stream) {
     }
     if (h->prec != CODAE_PREC_BF16) return CODAE_OK;
     CODAE_REQUIRE(b->shadow_w, "codae_sync_shadows: shadow_w missing");
-    return launch_cast_bf16(b->params, reinterpret_cast<bf16_t*>(b->shadow_w), h->n_param, (hipStream_t)stream);
+    int rc = launch_cast_bf16(b->params, reinterpret_cast<bf16_t*>(b->shadow_w), h->n_param, (hipStream_t)stream);
+    if (rc) return rc;
+    return refresh_transposed(h, b, (hipStream_t)stream);
 }
 
 int codae_forward(codae_handle h, const codae_buffers* b, const float* x, float* y, int32_t B, int32_t layer_lo,
@@ -693,9 +714,14 @@ static int update_impl(codae_handle h, const codae_buffers* b, const codae_hyper
     // contention) and the step from 1.76 to 1.84 ms, so this is opt-in (CODAE_DEFER_ADAM=1) only.
     const bool deferred = h->L >= 2 && h->L <= 64 && getenv("CODAE_SINGLE_STREAM") == nullptr && getenv("CODAE_DEFER_ADAM") != nullptr;
     if (!deferred) {
-        ProfScope prof(h, CODAE_K_ADAM, s);
-        return launch_clip_adam(b->params, b->grads, b->adam_m, b->adam_v, h->n_param, hyper, b->scalars + CODAE_S_GRAD_SQ,
-                                shadow, nullptr, s);
+        int rca;
+        {
+            ProfScope prof(h, CODAE_K_ADAM, s);
+            rca = launch_clip_adam(b->params, b->grads, b->adam_m, b->adam_v, h->n_param, hyper, b->scalars + CODAE_S_GRAD_SQ,
+                                   shadow, nullptr, s);
+        }
+        if (rca) return rca;
+        return refresh_transposed(h, b, s);
     }
     // Adam is a pure HBM pass (7 x 94 MB at C3) and the forward GEMMs that follow leave HBM mostly idle: update
     // the bias block and layer 0 here, the other layers on the side stream in forward order; the next forward's
@@ -729,6 +755,8 @@ static int update_impl(codae_handle h, const codae_buffers* b, const codae_hyper
         const int64_t end = (l + 1 < h->L) ? h->w_off[l + 1] : h->bias_begin;
         ProfScope prof(h, CODAE_K_ADAM, h->side);
         rc = seg(h->w_off[l], end - h->w_off[l], h->side);
+        if (rc) return rc;
+        rc = refresh_transposed(h, b, h->side, l, l + 1);
         if (rc) return rc;
         CODAE_HIP_CHECK(hipEventRecord(h->ev_adam[l], h->side));
         h->adam_pending[l] = true;
@@ -870,6 +898,13 @@ int codae_wgrad_bf16(const void* dy, const void* x, float* dW, void* slabs, int6
     if (rc) return rc;
     if (S > 1) return launch_reduce_slabs(reinterpret_cast<const float*>(slabs), S, (int64_t)N * K, dW, (int64_t)N * K, nullptr, (hipStream_t)stream);
     return CODAE_OK;
+}
+
+int codae_transpose_bf16(const void* src, void* dst, int32_t rows, int32_t cols, void* stream) {
+    CODAE_REQUIRE(src && dst && rows > 0 && cols > 0, "transpose: bad args");
+    const int64_t off = 0;
+    return launch_transpose_bf16(reinterpret_cast<const bf16_t*>(src), reinterpret_cast<bf16_t*>(dst), 1, &off, &rows, &cols,
+                                 (hipStream_t)stream);
 }
 
 int codae_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {

@@ -314,3 +314,16 @@ def test_ranking_loss_kernel_matches_oracle():
         got = rl.get(torch.tensor(pred, device=dev()), torch.tensor(fm, device=dev()), tuple(int(i) for i in idx))
         ref = O.ranking_loss(pred, fm, idx, list(ge["data_per_category"]), 16, val)
         assert abs(got - ref) <= 1e-3 * abs(ref) + 2.0 / (len(val) - 1), (got, ref)   # a near-tie may flip one comparison
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols", [(64, 64), (8, 8), (72, 200), (1536, 1536), (512, 16), (24, 1000)])
+def test_transpose_bf16(rows, cols):
+    """The transposed weight shadow the data-gradient GEMM reads: bit-exact W.t() (pure data movement)."""
+    import torch
+    from codae.hip import lib, check, ptr, current_stream
+    src = torch.randn(rows, cols, device="cuda").to(torch.bfloat16)
+    dst = torch.zeros(cols, rows, device="cuda", dtype=torch.bfloat16)
+    check(lib().codae_transpose_bf16(ptr(src), ptr(dst), rows, cols, current_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(dst, src.t().contiguous())
