@@ -248,6 +248,10 @@ int codae_dgrad_bf16(const void* dy, const void* W, const void* relu_src, void* 
                      int32_t M, int32_t N, int32_t K, void* stream);
 int codae_wgrad_bf16(const void* dy, const void* x, float* dW, void* slabs, int64_t slab_bytes,
                      int32_t M, int32_t N, int32_t K, void* stream);
+/* Tuning aid: with CODAE_GEMM_DBG=8 the forward-form bf16 GEMM stamps a 100 MHz wall clock per workgroup (entry, first
+ * MFMA phase, end of K loop, stores issued, stores retired, XCC id: 6 words each); this copies the first n_wg records to
+ * host memory (synchronises the device). */
+int codae_debug_gemm_timeline(uint64_t* host_out, int32_t n_wg);
 int codae_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* dst[c][r] = src[r][c] on bf16 matrices (rows, cols multiples of 8): the kernel that refreshes codae_buffers.shadow_wt
  * after each parameter update (W.t() in torch.nn.Linear's data gradient, embedding_denoising_autoencoder.py:137-151). */

@@ -90,6 +90,7 @@ PROTOTYPES = {
     "codae_dgrad_bf16": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
     "codae_wgrad_bf16": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P]),
     "codae_cast_f32_to_bf16": (C.c_int, [_P, _P, _I64, _P]),
+    "codae_debug_gemm_timeline": (C.c_int, [_P, _I32]),
     "codae_transpose_bf16": (C.c_int, [_P, _P, _I32, _I32, _P]),
 }
 

@@ -53,6 +53,21 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     return __builtin_bit_cast(bf16_t, b);
 }
 
+// two fp32 -> one packed bf16 pair with a single v_cvt_pk_bf16_f32 (round-to-nearest-even)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+// max(x, floor) as exactly one VALU op: fmaxf() puts a canonicalising v_max in front of the real one.
+// The GEMM epilogues clamp at `floor` = 0 (ReLU) or -inf (identity), so the ReLU switch costs no branch.
+__device__ __forceinline__ float clamp_below(float x, float floor) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(floor), "v"(x));
+    return r;
+}
+
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 // ---- generic exact-fp32 GEMM (gemm_f32.hip) --------------------------------
@@ -125,6 +140,7 @@ int launch_clip_adam(float* p, float* g, float* m, float* v, int64_t n, const co
 // dst[c][r] = src[r][c] for n bf16 matrices (element offsets off[i], shapes rows[i] x cols[i]) in one launch
 int launch_transpose_bf16(const bf16_t* src, bf16_t* dst, int n, const int64_t* off, const int* rows, const int* cols,
                           hipStream_t s);
+int gemm_bf16_timeline(unsigned long long* host_out, int n_wg);   // CODAE_GEMM_DBG=8 stamps
 int launch_clip_coef(const double* grad_sq, float max_norm, double* coef_out, hipStream_t s);
 int launch_reduce_slabs(const float* slabs, int n_slabs, int64_t slab_stride, float* out, int64_t n, double* sumsq,
                         hipStream_t s);

@@ -900,6 +900,10 @@ int codae_wgrad_bf16(const void* dy, const void* x, float* dW, void* slabs, int6
     return CODAE_OK;
 }
 
+int codae_debug_gemm_timeline(uint64_t* host_out, int32_t n_wg) {
+    return gemm_bf16_timeline(reinterpret_cast<unsigned long long*>(host_out), n_wg);
+}
+
 int codae_transpose_bf16(const void* src, void* dst, int32_t rows, int32_t cols, void* stream) {
     CODAE_REQUIRE(src && dst && rows > 0 && cols > 0, "transpose: bad args");
     const int64_t off = 0;

@@ -106,6 +106,25 @@ __device__ __forceinline__ void stage_tile(lds_char* tile, const bf16_t* __restr
     }
 }
 
+// ds_read_b64_tr_b16 issued as inline asm: a transposed LDS read the compiler knows about gets an
+// `s_waitcnt vmcnt(0)` in front of it while LDS-DMA loads are in flight (it cannot tell the images apart),
+// i.e. the wave would wait for the NEXT K-tile's loads before reading the current one.  The K loop
+// waits for these reads itself (wait_lgkm + settle below).
+template <int OFF>
+__device__ __forceinline__ s16x4 lds_read_tr16(const lds_char* p) {
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"((uint32_t)(uintptr_t)p), "n"(OFF));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+// hands fragment registers back to the compiler after the wait that covers their reads
+template <int N>
+__device__ __forceinline__ void settle(bf16x8 (&f)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(f[i]));
+}
+
 // One 8-element MFMA fragment of 16-row/col tile `t`, k-step `s` (32 deep) of an operand tile.
 template <int MODE, int R>
 __device__ __forceinline__ bf16x8 read_frag(const lds_char* tile, int t, int s, int lane) {
@@ -118,10 +137,8 @@ __device__ __forceinline__ bf16x8 read_frag(const lds_char* tile, int t, int s, 
         const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
         const int kr = 32 * s + 8 * g + q;
         const int off = kr * (2 * R) + (ks_to_lds_block<R>(t, kr) << 5) + 8 * p;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(tile + off));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(tile + off + 4 * 2 * R));
+        const s16x4 lo = lds_read_tr16<0>(tile + off);
+        const s16x4 hi = lds_read_tr16<4 * 2 * R>(tile + off);
         const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         return __builtin_bit_cast(bf16x8, v);
     }
@@ -187,13 +204,22 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
             for (int t = 0; t < TN; ++t) bfr[s][t] = read_frag<B_MODE, BN>(cur + A_BYTES, TN * wc + t, s, lane);
         }
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s) {
+            if constexpr (A_MODE == OP_KS || B_MODE == OP_KS) {
+                // asm-issued reads: k-step 0 is back once at most k-step 1's reads are outstanding
+                // (LDS returns in order; lgkmcnt saturates at 15)
+                constexpr int PER_STEP = TM * (A_MODE == OP_KS ? 2 : 1) + TN * (B_MODE == OP_KS ? 2 : 1);
+                if (s == 0) wait_lgkm<(PER_STEP < 15 ? PER_STEP : 15)>(); else wait_lgkm<0>();
+                if constexpr (A_MODE == OP_KS) settle(af[s]);
+                if constexpr (B_MODE == OP_KS) settle(bfr[s]);
+            }
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < TN; ++nt)
                     // swapped operands: D rows <-> output column (n), D cols <-> output row (m)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s][nt], af[s][mt], acc[mt][nt], 0, 0, 0);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -314,6 +340,7 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
         constexpr int PITCH = BN * 2 + 16;                 // bytes; rows stay 16-B aligned
         static_assert(BM * PITCH <= 2 * BUF_BYTES, "output tile must fit in the staging buffers");
         // (the K loop ended with vmcnt(0) + barrier: nobody reads the operand tiles any more)
+        const float floor_v = g.relu ? 0.f : -__builtin_inff();
 #pragma unroll
         for (int nt = 0; nt < TN; ++nt) {
             const int jl = (BN / WN) * wc + 16 * nt + g4;
@@ -323,14 +350,11 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
                 const int il = (BM / WM) * wr + 16 * mt + li;
-                float v0 = acc[mt][nt][0] + bj.x, v1 = acc[mt][nt][1] + bj.y;
-                float v2 = acc[mt][nt][2] + bj.z, v3 = acc[mt][nt][3] + bj.w;
-                if (g.relu) {
-                    v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-                }
+                const float v0 = clamp_below(acc[mt][nt][0] + bj.x, floor_v), v1 = clamp_below(acc[mt][nt][1] + bj.y, floor_v);
+                const float v2 = clamp_below(acc[mt][nt][2] + bj.z, floor_v), v3 = clamp_below(acc[mt][nt][3] + bj.w, floor_v);
                 u32x2 o;
-                o[0] = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
-                o[1] = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
+                o[0] = pack_bf16x2(v0, v1);
+                o[1] = pack_bf16x2(v2, v3);
                 *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(smem + il * PITCH + jl * 2) = o;
             }
         }
@@ -470,14 +494,16 @@ int gemm_bf16_tile_big(int M, int N, int split_k, bool k_strided = false) {
     if (env && env[0] == 'q') return 3;
     if (env && env[0] == 'c') return 4;
     const int64_t big = (int64_t)((M + 255) / 256) * ((N + 191) / 192) * split_k;
-    // measured (tools/bench_gemm.py, 8192 x 1536 x 1536): forward 38 us with 256x192/8 waves vs 41 with
-    // two 128x192 workgroups per CU; dgrad 51 vs 47; wgrad 60 vs 56
-    // ... but inside a dependent chain of layers (tools/bench_chain.py: inputs not cache-hot) the two-workgroup
-    // tile wins for the forward as well: 41-44 us per layer vs 44-48
-    // and the 8-wave phase-pipelined kernel wins the forward form (KC x KC): 39.5-41 us per layer in the chain vs
-    // 42-46; its k-strided forms are slower (dgrad 57 vs 47 us, wgrad 79 vs 56), so those stay on the 128x192 tile
+    // measured (tools/bench_gemm.py, 8192 x 1536 x 1536, us): tile            s     b     c     q
+    //   forward (KC x KC)                                                  46.3  38.4  40.2  37.0
+    //   dgrad through W itself (KC x KS; the engine uses the transposed shadow = forward form)
+    //                                                                      59.6  46.4  44.9  43.3
+    //   wgrad + slab reduce (KS x KS, split-K 5)                           68.1  55.1  55.3  53.9
+    // (before the transposed LDS reads went to inline asm the k-strided forms of q ran 53 / 62 us: the
+    // compiler drained vmcnt to 0 in front of each of them)
+    (void)k_strided;
     if (big < 160) return 0;
-    return k_strided ? 4 : 3;
+    return 3;
 }
 
 int gemm_bf16(const GemmBf16& g, hipStream_t s) {

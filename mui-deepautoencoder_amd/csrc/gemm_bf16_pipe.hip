@@ -136,6 +136,27 @@ __device__ __forceinline__ const bf16_t* half_src(const bf16_t* __restrict__ P, 
     }
 }
 
+// ds_read_b64_tr_b16 issued behind the compiler's back.  A transposed LDS read the compiler knows about
+// gets an `s_waitcnt vmcnt(0)` in front of it whenever LDS-DMA loads are in flight (it cannot tell the
+// images apart), which drains the whole 7-phase prefetch queue in every phase.  The kernel's own
+// protocol already orders these reads: every fragment is consumed only after the next phase_barrier()
+// (s_waitcnt lgkmcnt(0) + s_barrier), where settle() hands the registers back to the compiler.
+template <int OFF>
+__device__ __forceinline__ s16x4 lds_read_tr16(const lds_char* p) {
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"((uint32_t)(uintptr_t)p), "n"(OFF));
+    return v;
+}
+// after the wait that covers their reads: MFMAs consuming `f` cannot be scheduled above this point
+template <int N>
+__device__ __forceinline__ void settle(bf16x8 (&f)[N][2]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        asm volatile("" : "+v"(f[i][0]));
+        asm volatile("" : "+v"(f[i][1]));
+    }
+}
+
 // 8-element MFMA fragment: 16-wide tile `t` (local to the half image), k-step `s`.
 template <int MODE, int RH>
 __device__ __forceinline__ bf16x8 read_frag(const lds_char* img, int t, int s, int lane) {
@@ -148,14 +169,17 @@ __device__ __forceinline__ bf16x8 read_frag(const lds_char* img, int t, int s, i
         const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
         const int kr = 32 * s + 8 * g + q;
         const int off = kr * (2 * RH) + (ks_to_lds_block<RH>(t, kr) << 5) + 8 * p;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(img + off));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(img + off + 4 * 2 * RH));
+        const s16x4 lo = lds_read_tr16<0>(img + off);
+        const s16x4 hi = lds_read_tr16<4 * 2 * RH>(img + off);
         const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         return __builtin_bit_cast(bf16x8, v);
     }
 }
+
+// DBG = 8 build only: per-workgroup wall-clock stamps (100 MHz s_memrealtime) at entry, first MFMA phase,
+// end of the K loop, epilogue stores issued, stores retired; + the XCC the workgroup ran on
+constexpr int TIMELINE_WGS = 4096, TIMELINE_SLOTS = 6;
+__device__ unsigned long long g_timeline[TIMELINE_WGS * TIMELINE_SLOTS];
 
 template <int BM, int BN, int WM, int WN, int NLB, int A_MODE, int B_MODE, bool C_F32, int DBG = 0>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4)
@@ -195,7 +219,20 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
     auto a_img = [&](int tile, int h) { return smem + (tile & 1) * BUF + h * AH; };
     auto b_img = [&](int tile, int h) { return smem + (tile & 1) * BUF + 2 * AH + h * BH; };
     // timing-only ablations (compile-time; DBG = 0 in the shipped instantiations)
-    constexpr bool dbg_noload = DBG & 1, dbg_nomma = DBG & 2, dbg_nostore = DBG & 4;
+    constexpr bool dbg_noload = DBG & 1, dbg_nomma = DBG & 2, dbg_nostore = DBG & 4, dbg_time = DBG & 8;
+    auto stamp = [&](int slot) {
+        if constexpr (dbg_time) {
+            if (threadIdx.x == 0 && blockIdx.x < TIMELINE_WGS) g_timeline[blockIdx.x * TIMELINE_SLOTS + slot] = wall_clock64();
+        }
+    };
+    stamp(0);
+    if constexpr (dbg_time) {
+        if (threadIdx.x == 0 && blockIdx.x < TIMELINE_WGS) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_timeline[blockIdx.x * TIMELINE_SLOTS + 5] = xcc & 0xf;
+        }
+    }
     // per-lane LDS-DMA source pointers at k = 0 (loop invariant) and the per-K-tile advance
     const bool b_loader = (NLB == NW) || (w < NLB);
     const bf16_t* a_src[2][NA];
@@ -292,6 +329,7 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
     issue_a(2, 0);
     read_b(b0, 0, 0);
 
+    stamp(1);
     constexpr int N_MMA = 2 * TMH * TNH;
     constexpr int RD_A = 2 * TMH * (A_MODE == OP_KC ? 1 : 2), RD_B = 2 * TNH * (B_MODE == OP_KC ? 1 : 2);
     // one K-tile; `a0` holds A0(t), `a0n` receives A0(t+1).  Reads of a tile past the end fetch the
@@ -300,6 +338,8 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
         // P1: A0 x B0
         wait_half();
         phase_barrier();
+        if constexpr (A_MODE == OP_KS) settle(a0);
+        if constexpr (B_MODE == OP_KS) settle(b0);
         issue_b(t + 2, 0);
         read_a(a1, t, 1);
         mma(a0, b0, 0, 0);
@@ -307,6 +347,7 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
         // P2: A1 x B0
         wait_half();
         phase_barrier();
+        if constexpr (A_MODE == OP_KS) settle(a1);
         issue_a(t + 2, 1);
         read_b(b1, t, 1);
         mma(a1, b0, 1, 0);
@@ -314,6 +355,7 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
         // P3: A1 x B1
         wait_half();
         phase_barrier();
+        if constexpr (B_MODE == OP_KS) settle(b1);
         issue_b(t + 2, 1);
         read_a(a0n, t + 1, 0);
         mma(a1, b1, 1, 1);
@@ -333,6 +375,7 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
     }
     if (t < nkt) ktile(t, a0x, a0y);
     wait_vmcnt<0>();        // the trailing dummy loads must not outlive the kernel's use of LDS
+    stamp(2);
 
     // ---- epilogue: lane holds C[i][j .. j+3] of each 16 x 16 tile (swapped MFMA operands)
     const int li = lane & 15, g4 = (lane >> 4) * 4;
@@ -342,6 +385,7 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
         constexpr int NT = 64 * NW;
         constexpr int PITCH = BN * 2 + 16;
         static_assert(BM * PITCH <= 2 * BUF, "output tile must fit in the staging buffers");
+        const float floor_v = g.relu ? 0.f : -__builtin_inff();
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
@@ -355,13 +399,11 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
                     for (int mt = 0; mt < TMH; ++mt) {
                         const int il = mh * AHR + wr * (SM / 2) + 16 * mt + li;
                         const f32x4 a = acc[mh][mt][nh][nt];
-                        float v0 = a[0] + bj.x, v1 = a[1] + bj.y, v2 = a[2] + bj.z, v3 = a[3] + bj.w;
-                        if (g.relu) {
-                            v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-                        }
+                        const float v0 = clamp_below(a[0] + bj.x, floor_v), v1 = clamp_below(a[1] + bj.y, floor_v);
+                        const float v2 = clamp_below(a[2] + bj.z, floor_v), v3 = clamp_below(a[3] + bj.w, floor_v);
                         u32x2 o;
-                        o[0] = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
-                        o[1] = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
+                        o[0] = pack_bf16x2(v0, v1);
+                        o[1] = pack_bf16x2(v2, v3);
                         *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(smem + il * PITCH + jl * 2) = o;
                     }
             }
@@ -395,6 +437,8 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
                 }
             }
         }
+        stamp(3);
+        if constexpr (dbg_time) { wait_vmcnt<0>(); stamp(4); }
         if (g.colsum != nullptr) {
             __syncthreads();
             float* red = reinterpret_cast<float*>(smem_raw);
@@ -487,11 +531,19 @@ int gemm_bf16_pipe(const GemmBf16& g, int cfg, hipStream_t s) {
             case 5: return launch_dbg<5>(g, s);
             case 6: return launch_dbg<6>(g, s);
             case 7: return launch_dbg<7>(g, s);
+            case 8: return launch_dbg<8>(g, s);
             default: break;
         }
     }
     if (cfg == 1) return launch_pipe<256, 192, 4, 2, 6>(g, s);   // 8 waves (64 x 96 per wave), B halves by 6 loader waves
     return launch_pipe<256, 192, 2, 2, 4>(g, s);                 // 4 waves (128 x 96 per wave)
+}
+
+// copies the DBG = 8 stamps of the first n_wg workgroups (TIMELINE_SLOTS words each) to the host
+int gemm_bf16_timeline(unsigned long long* host_out, int n_wg) {
+    CODAE_REQUIRE(host_out && n_wg > 0 && n_wg <= TIMELINE_WGS, "timeline: bad args");
+    CODAE_HIP_CHECK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_timeline), (size_t)n_wg * TIMELINE_SLOTS * sizeof(unsigned long long)));
+    return CODAE_OK;
 }
 
 }  // namespace codae
