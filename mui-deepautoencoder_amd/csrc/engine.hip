@@ -350,11 +350,16 @@ int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi
     // =third uses a third stream - slower (1.84 ms).
     const char* rmode = getenv("CODAE_REDUCE_STREAM");
     const bool reduce_on_main = rmode != nullptr && rmode[0] == 'm';
+    const bool gemms_on_main = rmode != nullptr && rmode[0] == 'g';
     int lag_layer = -1;          // layer whose reduce is still to be issued on s
     for (int l = hi - 1; l >= lo; --l) {
         int rc;
         bool was_deferred = false;
-        if (dual) {
+        if (dual && gemms_on_main) {
+            // every GEMM on `s` (no gaps, no CU sharing); only the HBM-bound slab reduce goes to the side stream
+            rc = run_wgrad(h, b, l, rows, s, h->side, l & 1, slot_busy);
+            if (rc) return rc;
+        } else if (dual) {
             CODAE_HIP_CHECK(hipEventRecord(h->ev_ready, s));                // dA_l (and act[l]) are complete on s
             CODAE_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_ready, 0));
             if (reduce_on_main)
@@ -373,7 +378,7 @@ int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi
         const bool to_dx = !chain && !step_mode && dx != nullptr;
         if (chain || to_dx) {
             // the buffer dgrad_l writes, (l-1)%3 == (l+2)%3, may still be read by wgrad_{l+2}
-            if (dual && chain && w_pending[(l + 2) % 3] && l + 2 <= hi - 1) {
+            if (dual && !gemms_on_main && chain && w_pending[(l + 2) % 3] && l + 2 <= hi - 1) {
                 CODAE_HIP_CHECK(hipStreamWaitEvent(s, h->ev_w[(l + 2) % 3], 0));
                 w_pending[(l + 2) % 3] = false;
             }

@@ -151,7 +151,9 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
-    __shared__ __attribute__((aligned(16))) char smem_raw[2 * BUF_BYTES];
+    // LOSS: + {dataset row, mask id} of the tile's rows, fetched once at entry (two dependent loads that
+    // would otherwise sit in front of every row of the epilogue)
+    __shared__ __attribute__((aligned(16))) char smem_raw[2 * BUF_BYTES + (LOSS ? BM * 8 : 0)];
     lds_char* smem = (lds_char*)smem_raw;
 
     const int lane = threadIdx.x & 63;
@@ -178,6 +180,21 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if constexpr (LOSS) {
+        const LossFuse& L = g.loss;
+        int* rowinfo = reinterpret_cast<int*>(smem_raw + 2 * BUF_BYTES);
+        for (int r = threadIdx.x; r < BM; r += 64 * NW) {
+            const int i = i0 + r;
+            int src = -1, id = 0;
+            if (i < L.B && i < g.M) {
+                src = L.row_idx ? L.row_idx[i] : i;
+                if (L.mask_id != nullptr) id = L.mask_id[i];
+                else if (L.mask_to_use != nullptr) id = L.mask_to_use[(int64_t)src * L.nb_run + L.run];
+            }
+            rowinfo[2 * r] = src; rowinfo[2 * r + 1] = id;     // visible after the K loop's barriers
+        }
+    }
 
     if (nkt > 0) {
         stage_tile<A_MODE, BM, NW>(smem, g.A, g.lda, i0, g.M, kt_begin * BK, w, lane);
@@ -244,8 +261,33 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
         float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float sq = 0.f, sqp = 0.f;
         bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
+        constexpr int ITER = (HR + RL - 1) / RL;                // rows per thread per pass
+        const int* rowinfo = reinterpret_cast<const int*>(smem_raw + 2 * BUF_BYTES);
+        if (nkt == 0) __syncthreads();                          // (rowinfo otherwise published by the K loop's barriers)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
+            // all of this pass's x rows and mask bytes are requested before the tile half is staged:
+            // one exposed gather latency per pass instead of one per row
+            float4 xa[ITER], xb[ITER];
+            uint2 mk[ITER];
+            bool live[ITER];
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int r = rl + it * RL;
+                live[it] = false;
+                xa[it] = make_float4(0.f, 0.f, 0.f, 0.f); xb[it] = xa[it];
+                mk[it] = make_uint2(0x01010101u, 0x01010101u);
+                if (rl < RL && j < g.N && r < HR) {
+                    const int src_row = rowinfo[2 * (hh * HR + r)];
+                    if (src_row >= 0) {
+                        live[it] = true;
+                        const float* xp = L.data + (int64_t)src_row * L.io + j;
+                        xa[it] = *reinterpret_cast<const float4*>(xp);
+                        xb[it] = *reinterpret_cast<const float4*>(xp + 4);
+                        if (masked) mk[it] = *reinterpret_cast<const uint2*>(L.table + (int64_t)rowinfo[2 * (hh * HR + r) + 1] * L.io + j);
+                    }
+                }
+            }
             if (((BM / WM) * wr) / HR == hh) {
 #pragma unroll
                 for (int nt = 0; nt < TN; ++nt) {
@@ -263,23 +305,17 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
             }
             __syncthreads();
             if (rl < RL && j < g.N) {
-                for (int r = rl; r < HR; r += RL) {
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) {
+                    const int r = rl + it * RL;
                     const int i = i0 + hh * HR + r;
-                    if (i >= g.M) break;
+                    if (r >= HR || i >= g.M) break;
                     uint4 o = make_uint4(0u, 0u, 0u, 0u);
-                    if (i < L.B) {
-                        const int64_t src_row = L.row_idx ? L.row_idx[i] : i;
-                        const float* xp = L.data + src_row * L.io + j;
-                        const float4 xa = *reinterpret_cast<const float4*>(xp);
-                        const float4 xb = *reinterpret_cast<const float4*>(xp + 4);
+                    if (live[it]) {
                         const f32x4 ya = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(smem + r * PITCH + c * 32);
                         const f32x4 yb = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(smem + r * PITCH + c * 32 + 16);
-                        uint2 m = make_uint2(0x01010101u, 0x01010101u);
-                        if (masked) {
-                            const int id = L.mask_id ? L.mask_id[i] : L.mask_to_use[src_row * L.nb_run + L.run];
-                            m = *reinterpret_cast<const uint2*>(L.table + (int64_t)id * L.io + j);
-                        }
-                        const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                        const uint2 m = mk[it];
+                        const float xv[8] = {xa[it].x, xa[it].y, xa[it].z, xa[it].w, xb[it].x, xb[it].y, xb[it].z, xb[it].w};
                         const float yv[8] = {ya[0], ya[1], ya[2], ya[3], yb[0], yb[1], yb[2], yb[3]};
                         float gq[8];
 #pragma unroll
@@ -291,10 +327,8 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
                             if (mb == 0) sqp += se;
                             gq[k] = -2.f * d * L.inv_n;
                         }
-                        o.x = (uint32_t)f32_to_bf16(gq[0]) | ((uint32_t)f32_to_bf16(gq[1]) << 16);
-                        o.y = (uint32_t)f32_to_bf16(gq[2]) | ((uint32_t)f32_to_bf16(gq[3]) << 16);
-                        o.z = (uint32_t)f32_to_bf16(gq[4]) | ((uint32_t)f32_to_bf16(gq[5]) << 16);
-                        o.w = (uint32_t)f32_to_bf16(gq[6]) | ((uint32_t)f32_to_bf16(gq[7]) << 16);
+                        o.x = pack_bf16x2(gq[0], gq[1]); o.y = pack_bf16x2(gq[2], gq[3]);
+                        o.z = pack_bf16x2(gq[4], gq[5]); o.w = pack_bf16x2(gq[6], gq[7]);
 #pragma unroll
                         for (int k = 0; k < 8; ++k) cs[k] += gq[k];
                     }
@@ -465,6 +499,10 @@ int launch_cfg(const GemmBf16& g, hipStream_t s) {
 #define LAUNCH(AM, BMODE, CF) \
     hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, AM, BMODE, CF>), grid, block, 0, s, g, tiles_n, tiles_m * tiles_n, kt_total)
     if (g.loss.enabled) {
+        // (the fused-loss form is built for the one-workgroup-per-CU tiles only: its row table would push the
+        // 128 x 192 tile past the 80 KiB that lets two workgroups share a CU)
+        if constexpr (BM == 128 && BN == 192) { set_error("gemm_bf16: fused loss is not built for the 128 x 192 tile"); return CODAE_E_UNSUPPORTED; }
+        else
         hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, OP_KC, OP_KC, false, true>), grid, block, 0, s, g, tiles_n,
                            tiles_m * tiles_n, kt_total);
     } else if (g.a_mode == OP_KC && g.b_mode == OP_KC) { if (g.c_f32) LAUNCH(OP_KC, OP_KC, true); else LAUNCH(OP_KC, OP_KC, false); }
@@ -530,7 +568,6 @@ int gemm_bf16(const GemmBf16& g, hipStream_t s) {
     if (const char* d = getenv("CODAE_GEMM_DBG")) { GemmBf16 g2 = g; g2.dbg = atoi(d); if (g2.dbg) return gemm_bf16_pipe(g2, 0, s); }
     if (g.loss.enabled) {
         const int t = gemm_bf16_tile_big(g.M, g.N, 1);
-        if (t == 4) return launch_cfg<128, 192, 2, 2>(g, s);
         if (t) return launch_cfg<256, 192, 4, 2>(g, s);
         return launch_cfg<128, 128, 2, 2>(g, s);
     }
