@@ -123,7 +123,9 @@ int gemm_bf16(const GemmBf16& g, hipStream_t s);
 int gemm_bf16_pipe(const GemmBf16& g, int cfg, hipStream_t s);   // gemm_bf16_pipe.hip
 
 // ---- elementwise / reductions (elementwise.hip) ----------------------------
-int launch_gather_corrupt(const codae_batch* b, void* out, int out_bf16, hipStream_t s);
+// zero_ptr != null: also clears zero_n floats there (the bias-gradient block, ahead of a training step)
+int launch_gather_corrupt(const codae_batch* b, void* out, int out_bf16, hipStream_t s, float* zero_ptr = nullptr,
+                          int64_t zero_n = 0);
 int launch_cast_bf16(const float* src, bf16_t* dst, int64_t n, hipStream_t s);
 int launch_corrupt(const float* x, const float* mask, float* out, int64_t n, hipStream_t s);
 int launch_expand_masks(const int32_t* mask_id, const uint8_t* table, const int32_t* k_of_mask, int B, int io,
@@ -142,8 +144,9 @@ int launch_transpose_bf16(const bf16_t* src, bf16_t* dst, int n, const int64_t* 
                           hipStream_t s);
 int gemm_bf16_timeline(unsigned long long* host_out, int n_wg);   // CODAE_GEMM_DBG=8 stamps
 int launch_clip_coef(const double* grad_sq, float max_norm, double* coef_out, hipStream_t s);
+// sumsq != null: += sum out^2 (slot-scattered) and, with `extra`, += sum extra[0..n_extra)^2
 int launch_reduce_slabs(const float* slabs, int n_slabs, int64_t slab_stride, float* out, int64_t n, double* sumsq,
-                        hipStream_t s);
+                        hipStream_t s, const float* extra = nullptr, int n_extra = 0);
 int launch_finish_loss(double* scalars, double inv_n, hipStream_t s);
 int launch_cast_f32(const bf16_t* src, float* dst, int64_t n, hipStream_t s);
 // out[n] += sum_m src[m][n]

@@ -51,9 +51,12 @@ __global__ __launch_bounds__(NT) void gather_corrupt_kernel(const float* __restr
                                                             const uint8_t* __restrict__ table, int B, int io,
                                                             void* __restrict__ out,
                                                             const int32_t* __restrict__ mask_to_use, int nb_run,
-                                                            int run) {
+                                                            int run, float* __restrict__ zero_ptr, int64_t zero_n) {
     constexpr int W = VEC ? 4 : 1;
     const bool masked = (mask_id != nullptr) || (mask_to_use != nullptr);
+    // rides along in the first kernel of a training step: clear the bias-gradient block that the later
+    // GEMM epilogues accumulate into with atomics (saves a memset launch in the forward chain)
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < zero_n; e += (int64_t)gridDim.x * NT) zero_ptr[e] = 0.f;
     const int cols = io / W;
     const int64_t total = (int64_t)B * cols;
     for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < total; e += (int64_t)gridDim.x * NT) {
@@ -341,9 +344,13 @@ __global__ __launch_bounds__(NT) void clip_adam_kernel(float* __restrict__ p, co
 // sumsq += sum out[i]^2 so that clip_grad_norm_ needs no second pass over the gradient
 __global__ __launch_bounds__(NT) void reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs,
                                                           int64_t stride, float* __restrict__ out, int64_t n,
-                                                          double* __restrict__ sumsq) {
+                                                          double* __restrict__ sumsq, const float* __restrict__ extra,
+                                                          int n_extra) {
     __shared__ float red[4];
     float sq = 0.f;
+    // the layer's bias gradient (complete before this layer's weight-gradient GEMM started) joins the norm here
+    if (blockIdx.x == 0)
+        for (int e = threadIdx.x; e < n_extra; e += NT) sq += extra[e] * extra[e];
     const int64_t n4 = n / 4;
     for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < n4; e += (int64_t)gridDim.x * NT) {
         float4 a = reinterpret_cast<const float4*>(slabs)[e];
@@ -427,7 +434,7 @@ inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) ==
 
 }  // namespace
 
-int launch_gather_corrupt(const codae_batch* b, void* out, int out_bf16, hipStream_t s) {
+int launch_gather_corrupt(const codae_batch* b, void* out, int out_bf16, hipStream_t s, float* zero_ptr, int64_t zero_n) {
     CODAE_REQUIRE(b && b->data && out && b->B > 0 && b->io > 0, "gather_corrupt: bad batch");
     const bool masked = b->mask_id || b->mask_to_use;
     CODAE_REQUIRE(!masked || b->mask_table, "gather_corrupt: mask ids without mask_table");
@@ -437,7 +444,8 @@ int launch_gather_corrupt(const codae_batch* b, void* out, int out_bf16, hipStre
     const int64_t items = (int64_t)b->B * (vec ? b->io / 4 : b->io);
     const int grid = grid_for(items);
 #define GC(V, O) hipLaunchKernelGGL((gather_corrupt_kernel<V, O>), dim3(grid), dim3(NT), 0, s, b->data, b->row_idx, \
-                                    b->mask_id, b->mask_table, b->B, b->io, out, b->mask_to_use, b->nb_run, b->run)
+                                    b->mask_id, b->mask_table, b->B, b->io, out, b->mask_to_use, b->nb_run, b->run, \
+                                    zero_ptr, zero_ptr ? zero_n : 0)
     if (vec && out_bf16) GC(true, true);
     else if (vec) GC(true, false);
     else if (out_bf16) GC(false, true);
@@ -571,9 +579,10 @@ int launch_transpose_bf16(const bf16_t* src, bf16_t* dst, int n, const int64_t* 
 }
 
 int launch_reduce_slabs(const float* slabs, int n_slabs, int64_t stride, float* out, int64_t n, double* sumsq,
-                        hipStream_t s) {
+                        hipStream_t s, const float* extra, int n_extra) {
     CODAE_REQUIRE(slabs && out && n_slabs >= 1 && n > 0, "reduce_slabs: bad args");
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, s, slabs, n_slabs, stride, out, n, sumsq);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, s, slabs, n_slabs, stride, out, n, sumsq,
+                       (sumsq && extra) ? extra : nullptr, (sumsq && extra) ? n_extra : 0);
     CODAE_LAUNCH_CHECK();
     return CODAE_OK;
 }

@@ -48,6 +48,10 @@ struct codae_engine {
     mutable hipEvent_t ev_adam[64] = {};
     mutable bool adam_pending[64] = {};
     mutable hipEvent_t ev_norm = nullptr;
+    // the transposed weight shadow is refreshed on `side` after the update (only the NEXT backward reads it):
+    // ev_wt_src = Adam done on the caller's stream, ev_wt = transposes done on `side`
+    mutable hipEvent_t ev_wt_src = nullptr, ev_wt = nullptr;
+    mutable bool wt_pending = false;
     // single-GPU fused step: the slab reduce of every layer also accumulates sum g^2 (clip_grad_norm_)
     mutable bool norm_in_backward = false;
     mutable bool prof_on = false;
@@ -199,7 +203,8 @@ int run_wgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, hi
             {
                 ProfScope prof(e, CODAE_K_SLAB_REDUCE, red);
                 rc = launch_reduce_slabs(reinterpret_cast<const float*>(slab), S, (int64_t)N * K, dW, (int64_t)N * K,
-                                         e->norm_in_backward ? b->scalars + CODAE_S_GRAD_SQ : nullptr, red);
+                                         e->norm_in_backward ? b->scalars + CODAE_S_GRAD_SQ : nullptr, red,
+                                         b->grads + e->b_off[l], N);
             }
             if (rc) return rc;
             if (rs) {
@@ -231,7 +236,7 @@ int run_slab_reduce(const codae_engine* e, const codae_buffers* b, int l, int ro
     {
         ProfScope prof(e, CODAE_K_SLAB_REDUCE, rs);
         rc = launch_reduce_slabs(reinterpret_cast<const float*>(slab), S, (int64_t)N * K, b->grads + e->w_off[l], (int64_t)N * K,
-                                 e->norm_in_backward ? b->scalars + CODAE_S_GRAD_SQ : nullptr, rs);
+                                 e->norm_in_backward ? b->scalars + CODAE_S_GRAD_SQ : nullptr, rs, b->grads + e->b_off[l], N);
     }
     if (rc) return rc;
     CODAE_HIP_CHECK(hipEventRecord(e->ev_r[slot], rs));
@@ -293,11 +298,6 @@ int refresh_transposed(const codae_engine* e, const codae_buffers* b, hipStream_
     return CODAE_OK;
 }
 
-int zero_bias_grads(const codae_engine* e, const codae_buffers* b, hipStream_t s) {
-    CODAE_HIP_CHECK(hipMemsetAsync(b->grads + e->bias_begin, 0, (e->n_param - e->bias_begin) * sizeof(float), s));
-    return CODAE_OK;
-}
-
 // rows [B, rows) of a [rows][width] working-precision matrix -> 0 (bf16 mode pads the batch to 64)
 int zero_pad_rows(const codae_engine* e, void* base, int B, int rows, int width, hipStream_t s) {
     if (rows > B) {
@@ -320,7 +320,17 @@ int ensure_side_stream(const codae_engine* h) {
     CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     for (int i = 0; i < 3; ++i) CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_w[i], hipEventDisableTiming));
     CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_norm, hipEventDisableTiming));
+    CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_wt_src, hipEventDisableTiming));
+    CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_wt, hipEventDisableTiming));
     for (int l = 0; l < h->L; ++l) CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_adam[l], hipEventDisableTiming));
+    return CODAE_OK;
+}
+
+// stream s may touch shadow_w / shadow_wt once the side-stream transposes of the last update are done
+int wait_transposed(const codae_engine* h, hipStream_t s) {
+    if (!h->wt_pending) return CODAE_OK;
+    CODAE_HIP_CHECK(hipStreamWaitEvent(s, h->ev_wt, 0));
+    h->wt_pending = false;
     return CODAE_OK;
 }
 
@@ -338,6 +348,10 @@ int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi
     const int rows = h->rows_for(B);
     const bool dual = getenv("CODAE_SINGLE_STREAM") == nullptr;
     const bool reduce_stream = false;
+    {
+        int rcw = wait_transposed(h, s);      // the dgrads read shadow_wt
+        if (rcw) return rcw;
+    }
     if (dual) {
         int rc = ensure_side_stream(h);
         if (rc) return rc;
@@ -491,6 +505,7 @@ int codae_destroy(codae_handle h) {
         for (int i = 0; i < 3; ++i) (void)hipEventDestroy(h->ev_w[i]);
         (void)hipStreamSynchronize(h->side2);
         (void)hipEventDestroy(h->ev_norm);
+        (void)hipEventDestroy(h->ev_wt_src); (void)hipEventDestroy(h->ev_wt);
         for (int l = 0; l < h->L; ++l) (void)hipEventDestroy(h->ev_adam[l]);
         (void)hipEventDestroy(h->ev_join2);
         for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(h->ev_g[i]); (void)hipEventDestroy(h->ev_r[i]); }
@@ -554,6 +569,10 @@ int codae_sync_shadows(codae_handle h, const codae_buffers* b, void* stream) {
     }
     if (h->prec != CODAE_PREC_BF16) return CODAE_OK;
     CODAE_REQUIRE(b->shadow_w, "codae_sync_shadows: shadow_w missing");
+    {
+        int rcw = wait_transposed(h, (hipStream_t)stream);
+        if (rcw) return rcw;
+    }
     int rc = launch_cast_bf16(b->params, reinterpret_cast<bf16_t*>(b->shadow_w), h->n_param, (hipStream_t)stream);
     if (rc) return rc;
     return refresh_transposed(h, b, (hipStream_t)stream);
@@ -628,7 +647,9 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
     const bool bf = h->prec == CODAE_PREC_BF16;
     {
         ProfScope prof(h, CODAE_K_GATHER, s);
-        rc = launch_gather_corrupt(batch, act_ptr(h, b, 0), bf, s);
+        // training step: the bias-gradient block (accumulated with atomics from the loss on) is cleared here
+        rc = launch_gather_corrupt(batch, act_ptr(h, b, 0), bf, s, hyper != nullptr ? b->grads + h->bias_begin : nullptr,
+                                   h->n_param - h->bias_begin);
     }
     if (rc) return rc;
     rc = zero_pad_rows(h, act_ptr(h, b, 0), B, rows, h->in[0], s);
@@ -640,8 +661,6 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
         const bool last = (l == L - 1);
         if (last && fuse_loss) {
             rc = wait_layer_params(h, l, s);
-            if (rc) return rc;
-            rc = zero_bias_grads(h, b, s);
             if (rc) return rc;
             const double n_glob = (double)(hyper->loss_scale_rows > 0.f ? hyper->loss_scale_rows : (float)B) * batch->io;
             GemmBf16 g{};
@@ -667,8 +686,6 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
         if (rc) return rc;
     }
     if (hyper != nullptr) {
-        rc = zero_bias_grads(h, b, s);
-        if (rc) return rc;
         const double n_glob = (double)(hyper->loss_scale_rows > 0.f ? hyper->loss_scale_rows : (float)B) * batch->io;
         rc = zero_pad_rows(h, dact_ptr(h, b, L - 1), B, rows, batch->io, s);
         if (rc) return rc;
@@ -700,12 +717,15 @@ int codae_step_backward(codae_handle h, const codae_buffers* b, int32_t B, int32
 static int update_impl(codae_handle h, const codae_buffers* b, const codae_hyper* hyper, hipStream_t s, bool weights_norm_done) {
     CODAE_REQUIRE(h && b && hyper, "codae_step_update: null argument");
     CODAE_REQUIRE(b->params && b->grads && b->adam_m && b->adam_v && b->scalars, "codae_step_update: buffer missing");
+    {
+        int rcw = wait_transposed(h, s);      // Adam rewrites shadow_w, which a pending transpose still reads
+        if (rcw) return rcw;
+    }
     if (hyper->max_grad_norm > 0.f) {
         ProfScope prof(h, CODAE_K_SUMSQ, s);
         int rc;
         if (weights_norm_done) {
-            // sum g^2 of every weight gradient was accumulated by the slab reduces: add the bias block
-            rc = launch_sumsq(b->grads + h->bias_begin, h->n_param - h->bias_begin, b->scalars + CODAE_S_GRAD_SQ, s);
+            rc = CODAE_OK;     // sum g^2 of every weight and bias gradient was accumulated by the slab reduces
         } else {
             CODAE_HIP_CHECK(hipMemsetAsync(b->scalars + CODAE_S_GRAD_SQ, 0, sizeof(double), s));
             CODAE_HIP_CHECK(hipMemsetAsync(b->scalars + CODAE_S_GRAD_SQ_SLOTS, 0, CODAE_S_N_SLOTS * sizeof(double), s));
@@ -726,7 +746,19 @@ static int update_impl(codae_handle h, const codae_buffers* b, const codae_hyper
                                    shadow, nullptr, s);
         }
         if (rca) return rca;
-        return refresh_transposed(h, b, s);
+        if (h->prec != CODAE_PREC_BF16 || b->shadow_wt == nullptr || h->L < 2) return CODAE_OK;
+        if (getenv("CODAE_SINGLE_STREAM") != nullptr || getenv("CODAE_SYNC_WT") != nullptr) return refresh_transposed(h, b, s);
+        // nothing reads the transposed shadow before the next backward: refresh it on the side stream, beside
+        // the next forward (19 us of HBM-bound copying at C3 off the critical path)
+        int rcs = ensure_side_stream(h);
+        if (rcs) return rcs;
+        CODAE_HIP_CHECK(hipEventRecord(h->ev_wt_src, s));
+        CODAE_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_wt_src, 0));
+        rcs = refresh_transposed(h, b, h->side);
+        if (rcs) return rcs;
+        CODAE_HIP_CHECK(hipEventRecord(h->ev_wt, h->side));
+        h->wt_pending = true;
+        return CODAE_OK;
     }
     // Adam is a pure HBM pass (7 x 94 MB at C3) and the forward GEMMs that follow leave HBM mostly idle: update
     // the bias block and layer 0 here, the other layers on the side stream in forward order; the next forward's
@@ -775,6 +807,8 @@ int codae_step_update(codae_handle h, const codae_buffers* b, const codae_hyper*
 
 int codae_join(codae_handle h, void* stream) {
     CODAE_REQUIRE(h != nullptr, "codae_join: null handle");
+    int rc = wait_transposed(h, (hipStream_t)stream);
+    if (rc) return rc;
     return wait_all_params(h, (hipStream_t)stream);
 }
 
