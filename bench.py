@@ -20,7 +20,8 @@ with hipEvent pairs recorded around every launch of the timed region on the laun
 (codae_profile_begin/_end); achieved = 2*M*N*K / mean launch time.  (dgrad and wgrad launches of a
 layer run concurrently on two streams; their overlapping times are listed under by_kernel.)  `cpu_baseline`: the numpy
 oracle (oracle/dae_oracle.py, a port of the reference's math; used here only as the thing timed)
-on the host cores, bounded sample.
+on the host cores, bounded sample; `cpu_baseline.torch_cpu`: the same step as plain torch CPU ops
+(the stack the reference runs on), timed beside it.
 """
 import argparse
 import json
@@ -91,10 +92,53 @@ def cpu_baseline(schedule, data, blank, io, slots, budget_s=18.0):
         n += 1
         if t_sum > 2 * budget_s:
             break
-    return {"value": B * n / t_sum, "unit": "samples/s", "cores": int(threads), "kind": "port",
-            "sample": "%d timed steps (1 warm-up) of the numpy oracle step at the same 3x512 / batch %d workload, fp32"
-                      % (n, B),
-            "ms_per_step": 1e3 * t_sum / n}
+    out = {"value": B * n / t_sum, "unit": "samples/s", "cores": int(threads), "kind": "port",
+           "sample": "%d timed steps (1 warm-up) of the numpy oracle step at the same 3x512 / batch %d workload, fp32"
+                     % (n, B),
+           "ms_per_step": 1e3 * t_sum / n}
+    out["torch_cpu"] = torch_cpu_baseline(schedule, x, fmask, budget_s=8.0)
+    return out
+
+
+def torch_cpu_baseline(schedule, x_np, fmask_np, budget_s=8.0):
+    """The same step as plain torch CPU ops (nn.Linear stack, MSELoss, clip_grad_norm_, Adam): the
+    stack the reference itself runs on (script/train_dae_on_embedding.py:198-215), timed beside the oracle."""
+    import torch
+    torch.manual_seed(0)
+    layers = []
+    for k, n, relu in schedule:
+        lin = torch.nn.Linear(k, n)
+        torch.nn.init.xavier_uniform_(lin.weight)
+        torch.nn.init.zeros_(lin.bias)
+        layers.append(lin)
+        if relu:
+            layers.append(torch.nn.ReLU(inplace=True))
+    model = torch.nn.Sequential(*layers)
+    opt = torch.optim.Adam(model.parameters(), lr=LR, weight_decay=WD)
+    crit = torch.nn.MSELoss(reduction="mean")
+    x = torch.from_numpy(x_np)
+    m = torch.from_numpy(fmask_np).to(torch.float32)
+
+    def step():
+        opt.zero_grad()
+        y = model(x * m)
+        loss = crit(x, y)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), CLIP)
+        opt.step()
+        return float(loss.detach())
+
+    t0 = time.perf_counter()
+    step()
+    warm = time.perf_counter() - t0
+    n, t_sum = 0, 0.0
+    while n < 2 or (t_sum + warm < budget_s and n < 20):
+        t0 = time.perf_counter()
+        step()
+        t_sum += time.perf_counter() - t0
+        n += 1
+    return {"value": x.shape[0] * n / t_sum, "unit": "samples/s", "threads": int(torch.get_num_threads()),
+            "ms_per_step": 1e3 * t_sum / n, "sample": "%d timed steps (1 warm-up), torch %s CPU fp32" % (n, torch.__version__)}
 
 
 def main():
