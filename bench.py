@@ -225,7 +225,7 @@ def main():
     barrier()
     kernel_events = not args.no_kernel_events
     if kernel_events:
-        tr.engine.profile_begin(("gemm_fwd", "gemm_dgrad", "gemm_wgrad"), max_records=32 * args.steps + 64)
+        tr.engine.profile_begin(("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "loss"), max_records=32 * args.steps + 64)
     t0 = time.perf_counter()
     for st in range(args.warmup, total_steps):
         tr.train_batch(idx_steps[st], run=0)
@@ -266,6 +266,8 @@ def main():
                 by[name] = {"launches": len(ms), "mean_ms": mean_ms, "min_ms": float(np.min(ms)),
                             "tflops": gemm_flops / (mean_ms * 1e-3) / 1e12,
                             "ms_per_step": float(np.sum(ms)) / args.steps}
+            # ("loss" in the fused bf16 step = the LAST forward GEMM with the MSE loss in its epilogue: GEMM flops
+            # plus a gather of the 50 MB target rows, so it is listed apart from the plain forward launches)
             # The forward GEMM class (the "3-slot x 512 encoder GEMM" of BASELINE.json) is the kernel the
             # roofline is quoted on: its launches run alone on the chip.  The dgrad and wgrad launches of one
             # layer run CONCURRENTLY on two streams, so their per-launch event times overlap (by_kernel keeps them).

@@ -180,7 +180,7 @@ enum {
     CODAE_K_GEMM_FWD = 0,   /* y = act(x W^T + b) */
     CODAE_K_GEMM_DGRAD = 1, /* dx = (dy W) * relu' */
     CODAE_K_GEMM_WGRAD = 2, /* dW = dy^T x (the GEMM launch only) */
-    CODAE_K_LOSS = 3,
+    CODAE_K_LOSS = 3,       /* MSE loss fwd+bwd; in the fused bf16 step: the last forward GEMM with the loss in its epilogue */
     CODAE_K_GATHER = 4,
     CODAE_K_SUMSQ = 5,
     CODAE_K_ADAM = 6,

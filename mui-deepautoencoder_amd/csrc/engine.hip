@@ -675,7 +675,7 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
             g.loss.table = batch->mask_table; g.loss.io = batch->io; g.loss.B = B; g.loss.inv_n = (float)(1.0 / n_glob);
             g.loss.scalars = b->scalars;
             {
-                ProfScope prof(h, CODAE_K_GEMM_FWD, s);
+                ProfScope prof(h, CODAE_K_LOSS, s);     // last layer + loss in one launch: its own class, not a plain forward GEMM
                 rc = gemm_bf16(g, s);
             }
             if (rc) return rc;

@@ -181,7 +181,10 @@ __device__ __forceinline__ bf16x8 read_frag(const lds_char* img, int t, int s, i
 constexpr int TIMELINE_WGS = 4096, TIMELINE_SLOTS = 6;
 __device__ unsigned long long g_timeline[TIMELINE_WGS * TIMELINE_SLOTS];
 
-template <int BM, int BN, int WM, int WN, int NLB, int A_MODE, int B_MODE, bool C_F32, int DBG = 0>
+// EPI (bf16 output only): 1 = forward epilogue (bias + ReLU), 2 = data-gradient epilogue (ReLU mask from the saved
+// activation + column sums = bias gradient), 0 = everything decided at run time.  Apart from trimming the forward's
+// epilogue this gives the forward and the data-gradient launches distinct kernel symbols in rocprofv3 traces.
+template <int BM, int BN, int WM, int WN, int NLB, int A_MODE, int B_MODE, bool C_F32, int DBG = 0, int EPI = 0>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4)
 void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
     constexpr int NW = WM * WN;
@@ -419,7 +422,7 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
                 if (i >= g.M) break;
                 const u32x4 lv = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(smem + r * PITCH + c * 16);
                 uint4 v = make_uint4(lv[0], lv[1], lv[2], lv[3]);
-                if (g.relu_src != nullptr) {
+                if (EPI != 1 && g.relu_src != nullptr) {
                     const uint4 h = *reinterpret_cast<const uint4*>(g.relu_src + (int64_t)i * g.ld_relu + j);
                     auto keep = [](uint32_t val, uint32_t hh) -> uint32_t {
                         const uint32_t lo = ((hh & 0x8000u) == 0 && (hh & 0x7fffu) != 0) ? 0x0000ffffu : 0u;
@@ -429,7 +432,7 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
                     v.x = keep(v.x, h.x); v.y = keep(v.y, h.y); v.z = keep(v.z, h.z); v.w = keep(v.w, h.w);
                 }
                 *reinterpret_cast<uint4*>(Cb + (int64_t)i * g.ldc + j) = v;
-                if (g.colsum != nullptr) {
+                if (EPI != 1 && g.colsum != nullptr) {
                     cs[0] += bf16_to_f32((bf16_t)(v.x & 0xffff)); cs[1] += bf16_to_f32((bf16_t)(v.x >> 16));
                     cs[2] += bf16_to_f32((bf16_t)(v.y & 0xffff)); cs[3] += bf16_to_f32((bf16_t)(v.y >> 16));
                     cs[4] += bf16_to_f32((bf16_t)(v.z & 0xffff)); cs[5] += bf16_to_f32((bf16_t)(v.z >> 16));
@@ -439,7 +442,7 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
         }
         stamp(3);
         if constexpr (dbg_time) { wait_vmcnt<0>(); stamp(4); }
-        if (g.colsum != nullptr) {
+        if (EPI != 1 && g.colsum != nullptr) {
             __syncthreads();
             float* red = reinterpret_cast<float*>(smem_raw);
             static_assert(RL * BN * 4 <= 2 * BUF, "reduction scratch must fit");
@@ -492,12 +495,15 @@ int launch_pipe(const GemmBf16& g, hipStream_t s) {
     const int64_t nwg = (int64_t)tiles_m * tiles_n * g.split_k;
     CODAE_REQUIRE(nwg < (1 << 30), "gemm_bf16: grid too large");
     dim3 grid((unsigned)nwg), block(64 * WM * WN);
-#define LAUNCH(AM, BMODE, CF) \
-    hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, WM, WN, NLB, AM, BMODE, CF>), grid, block, 0, s, g, tiles_n, tiles_m * tiles_n, kt_total)
-    if (g.a_mode == OP_KC && g.b_mode == OP_KC) { if (g.c_f32) LAUNCH(OP_KC, OP_KC, true); else LAUNCH(OP_KC, OP_KC, false); }
-    else if (g.a_mode == OP_KC && g.b_mode == OP_KS) { if (g.c_f32) LAUNCH(OP_KC, OP_KS, true); else LAUNCH(OP_KC, OP_KS, false); }
-    else if (g.a_mode == OP_KS && g.b_mode == OP_KS) { if (g.c_f32) LAUNCH(OP_KS, OP_KS, true); else LAUNCH(OP_KS, OP_KS, false); }
+#define LAUNCH(AM, BMODE, CF, EP) \
+    hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, WM, WN, NLB, AM, BMODE, CF, 0, EP>), grid, block, 0, s, g, tiles_n, tiles_m * tiles_n, kt_total)
+#define LAUNCH_BF16(AM, BMODE) do { if (bwd_epi) LAUNCH(AM, BMODE, false, 2); else LAUNCH(AM, BMODE, false, 1); } while (0)
+    const bool bwd_epi = g.relu_src != nullptr || g.colsum != nullptr;
+    if (g.a_mode == OP_KC && g.b_mode == OP_KC) { if (g.c_f32) LAUNCH(OP_KC, OP_KC, true, 0); else LAUNCH_BF16(OP_KC, OP_KC); }
+    else if (g.a_mode == OP_KC && g.b_mode == OP_KS) { if (g.c_f32) LAUNCH(OP_KC, OP_KS, true, 0); else LAUNCH_BF16(OP_KC, OP_KS); }
+    else if (g.a_mode == OP_KS && g.b_mode == OP_KS) { if (g.c_f32) LAUNCH(OP_KS, OP_KS, true, 0); else LAUNCH_BF16(OP_KS, OP_KS); }
     else { set_error("gemm_bf16: operand mode combination not built"); return CODAE_E_UNSUPPORTED; }
+#undef LAUNCH_BF16
 #undef LAUNCH
     CODAE_LAUNCH_CHECK();
     return CODAE_OK;
