@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not record per-launch hipEvents in the timed region (roofline then null)")
     ap.add_argument("--buckets", type=int, default=4)
+    ap.add_argument("--all-kernel-events", action="store_true")
     args = ap.parse_args()
 
     import numpy as np
@@ -180,7 +181,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        from codae.train import init_rccl_process_group
+        init_rccl_process_group(dev)
 
     from codae.train import HipEmbeddingTrainer
 
@@ -225,10 +227,15 @@ def main():
     barrier()
     kernel_events = not args.no_kernel_events
     if kernel_events:
-        tr.engine.profile_begin(("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "loss"), max_records=32 * args.steps + 64)
+        # hipEvent pairs cost 2-4 us per launch INSIDE the timed region (they break back-to-back dispatch): by
+        # default only the kernel the roofline is quoted on is timed (9 launches per step, ~2 % of the step);
+        # --all-kernel-events adds the other GEMM classes (30 launches per step: ~10 % slower steps)
+        classes = ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "loss") if args.all_kernel_events else ("gemm_fwd",)
+        tr.engine.profile_begin(classes, max_records=32 * args.steps + 64)
     t0 = time.perf_counter()
     for st in range(args.warmup, total_steps):
         tr.train_batch(idx_steps[st], run=0)
+    enqueue_s = time.perf_counter() - t0      # host time to ENQUEUE the timed steps (no device sync yet)
     barrier()
     elapsed = time.perf_counter() - t0
     prof = tr.engine.profile_end() if kernel_events else {}
@@ -256,6 +263,7 @@ def main():
                        "step_tflops_algorithmic": fps * B / 1e12,
                        "mfma_roofline_frac_whole_step": (fps * value / world) / (peak * 1e12)},
             "final_loss": loss, "final_grad_norm": gnorm,
+            "host_enqueue_ms_per_step": 1e3 * enqueue_s / args.steps,
         }
         roof = None
         if prof:

@@ -166,6 +166,18 @@ int codae_step_update(codae_handle h, const codae_buffers* bufs, const codae_hyp
 /* Make `stream` wait for everything the engine still has in flight on its own streams (the per-layer Adam
  * kernels of the last update run beside the next forward).  Call before reading parameters, Adam state or
  * gradients from another stream / the host. */
+/* Data-parallel form of codae_step_backward: returns WITHOUT making `stream` wait for the engine's side stream.
+ * When it returns, the weight gradients of [layer_lo, layer_hi) are complete in enqueue order on the stream
+ * codae_side_stream() reports (on `stream` itself when that is NULL), the bias and data gradients on `stream`.
+ * The caller orders its consumer (a bucket all-reduce) behind the side stream, goes on with the next bucket, and calls
+ * codae_join() before anything on `stream` reads the weight gradients (codae_step_update does so itself).
+ * Replaces the autograd hooks torch's DistributedDataParallel would put on loss.backward()
+ * (script/train_dae_on_embedding.py:210). */
+int codae_step_backward_async(codae_handle h, const codae_buffers* bufs, int32_t B, int32_t layer_lo,
+                              int32_t layer_hi, void* stream);
+/* The stream the weight-gradient GEMMs and slab reduces run on (created on first use); NULL when the engine runs
+ * everything on the caller's stream (CODAE_SINGLE_STREAM). Owned by the handle. */
+int codae_side_stream(codae_handle h, void** stream_out);
 int codae_join(codae_handle h, void* stream);
 /* all three, single GPU */
 int codae_train_step(codae_handle h, const codae_buffers* bufs, const codae_batch* batch,

@@ -187,9 +187,21 @@ class DaeEngine:
             check(self._lib.codae_step_forward_loss(self._h, C.byref(self.bufs), C.byref(batch), C.byref(hyper),
                                                     ptr(out_y), current_stream()))
 
-    def step_backward(self, B, layer_lo, layer_hi):
+    def step_backward(self, B, layer_lo, layer_hi, join=True):
+        """join=False (data parallel): return without making the current stream wait for the side stream; the
+        weight gradients of the range are then ordered on `side_stream()` (see codae_step_backward_async)."""
+        fn = self._lib.codae_step_backward if join else self._lib.codae_step_backward_async
         with torch.cuda.device(self.device):
-            check(self._lib.codae_step_backward(self._h, C.byref(self.bufs), B, layer_lo, layer_hi, current_stream()))
+            check(fn(self._h, C.byref(self.bufs), B, layer_lo, layer_hi, current_stream()))
+
+    def side_stream(self):
+        """torch view of the engine's side stream (None when it runs everything on the caller's stream)."""
+        if getattr(self, "_side_ext", None) is None:
+            out = C.c_void_p()
+            with torch.cuda.device(self.device):
+                check(self._lib.codae_side_stream(self._h, C.byref(out)))
+            self._side_ext = torch.cuda.ExternalStream(out.value, device=self.device) if out.value else False
+        return self._side_ext or None
 
     def step_update(self, hyper):
         with torch.cuda.device(self.device):

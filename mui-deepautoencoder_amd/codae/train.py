@@ -62,6 +62,26 @@ def default_buckets(n_layers, n_buckets=4):
     return out
 
 
+def init_rccl_process_group(device, **kw):
+    """`torch.distributed.init_process_group("nccl")` (= RCCL on ROCm) with the collectives on HIGH-priority streams.
+
+    Why it matters here: the ROCm runtime multiplexes the streams of one priority level onto a few hardware queues,
+    and a `hipStreamWaitEvent` is a barrier packet that holds up EVERYTHING behind it on its hardware queue.  With
+    torch's default (normal-priority) collective stream sharing the queue of the compute stream, each bucket
+    all-reduce's wait for the engine's side stream stalled the dgrad chain for ~90 us (rocprofv3 trace, forced
+    one-rank collectives).  High priority puts the collective stream in its own queue pool: compute stream normal,
+    engine side stream low, collectives high."""
+    import torch.distributed as dist
+    opts = None
+    try:
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+    except Exception:                                   # builds without the NCCL/RCCL process group
+        opts = None
+    if opts is not None:
+        kw.setdefault("pg_options", opts)
+    dist.init_process_group(backend="nccl", device_id=device, **kw)
+
+
 class DataParallel:
     """Bucketed gradient all-reduce around an engine's step_* phases.
 
@@ -92,10 +112,22 @@ class DataParallel:
             eng.step_backward(B, 0, eng.L)
             return
         works = []
-        for lo, hi in self.buckets:
-            eng.step_backward(B, lo, hi)
-            works.append(self.dist.all_reduce(self._weight_span(lo, hi), op=self.dist.ReduceOp.SUM,
-                                              group=self.group, async_op=True))
+        side = eng.side_stream() if hasattr(eng, "side_stream") else None
+        if side is not None:
+            # No join between buckets: the bucket's weight gradients are complete on the engine's side stream, so the
+            # collective is ordered behind THAT stream while the main stream goes straight on with the next bucket.
+            import torch
+            for lo, hi in self.buckets:
+                eng.step_backward(B, lo, hi, join=False)
+                with torch.cuda.stream(side):
+                    works.append(self.dist.all_reduce(self._weight_span(lo, hi), op=self.dist.ReduceOp.SUM,
+                                                      group=self.group, async_op=True))
+            eng.join()
+        else:
+            for lo, hi in self.buckets:
+                eng.step_backward(B, lo, hi)
+                works.append(self.dist.all_reduce(self._weight_span(lo, hi), op=self.dist.ReduceOp.SUM,
+                                                  group=self.group, async_op=True))
         # bias gradients of layer l are finished by the dgrad of layer l+1: reduce the block last
         works.append(self.dist.all_reduce(eng.grads[eng.b_off[0]:eng.n_param], op=self.dist.ReduceOp.SUM,
                                           group=self.group, async_op=True))

@@ -52,6 +52,10 @@ struct codae_engine {
     // ev_wt_src = Adam done on the caller's stream, ev_wt = transposes done on `side`
     mutable hipEvent_t ev_wt_src = nullptr, ev_wt = nullptr;
     mutable bool wt_pending = false;
+    // dA buffer i is still being read by a side-stream wgrad (event ev_w[i]); kept across calls so that a backward
+    // issued bucket by bucket without joins (codae_step_backward_async) stays ordered
+    mutable bool w_pending[3] = {false, false, false};
+    mutable bool side_dirty = false;      // side-stream work not yet joined into the caller's stream
     // single-GPU fused step: the slab reduce of every layer also accumulates sum g^2 (clip_grad_norm_)
     mutable bool norm_in_backward = false;
     mutable bool prof_on = false;
@@ -309,8 +313,16 @@ int zero_pad_rows(const codae_engine* e, void* base, int B, int rows, int width,
 
 int ensure_side_stream(const codae_engine* h) {
     if (h->side != nullptr) return CODAE_OK;
-    CODAE_HIP_CHECK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-    CODAE_HIP_CHECK(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
+    // The side streams must land on a hardware queue of their own: two streams that share one execute serially
+    // with ~11 us between dependent kernels (seen with RCCL initialised: every stream of the process on one queue,
+    // the whole backward serial).  The runtime keeps a separate queue pool per priority level, so the side streams
+    // take the LOWEST priority: never the queue of the caller's normal-priority stream, nor of RCCL's
+    // high-priority ones; and the dgrad chain (critical path, caller's stream) is dispatched first.
+    int prio_least = 0, prio_greatest = 0;
+    CODAE_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    const int prio = getenv("CODAE_SIDE_PRIORITY") ? atoi(getenv("CODAE_SIDE_PRIORITY")) : prio_least;
+    CODAE_HIP_CHECK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio));
+    CODAE_HIP_CHECK(hipStreamCreateWithPriority(&h->side2, hipStreamNonBlocking, prio));
     CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming));
     for (int i = 0; i < 2; ++i) {
         CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_g[i], hipEventDisableTiming));
@@ -323,6 +335,18 @@ int ensure_side_stream(const codae_engine* h) {
     CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_wt_src, hipEventDisableTiming));
     CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_wt, hipEventDisableTiming));
     for (int l = 0; l < h->L; ++l) CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_adam[l], hipEventDisableTiming));
+    return CODAE_OK;
+}
+
+// s waits for everything the backward put on the side streams
+int join_side(const codae_engine* h, hipStream_t s) {
+    if (!h->side_dirty || h->side == nullptr) return CODAE_OK;
+    CODAE_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
+    CODAE_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join, 0));
+    CODAE_HIP_CHECK(hipEventRecord(h->ev_join2, h->side2));
+    CODAE_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join2, 0));
+    for (int i = 0; i < 3; ++i) h->w_pending[i] = false;
+    h->side_dirty = false;
     return CODAE_OK;
 }
 
@@ -344,7 +368,7 @@ int wait_transposed(const codae_engine* h, hipStream_t s) {
 // rotating buffers: dgrad_l writes buffer (l-1)%3, which wgrad_{l+2} was reading, so it waits for
 // that wgrad's event only.  The call returns with `s` waiting for every side-stream kernel.
 int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi, float* dx, bool step_mode,
-                   hipStream_t s) {
+                   hipStream_t s, bool join = true) {
     const int rows = h->rows_for(B);
     const bool dual = getenv("CODAE_SINGLE_STREAM") == nullptr;
     const bool reduce_stream = false;
@@ -356,7 +380,7 @@ int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi
         int rc = ensure_side_stream(h);
         if (rc) return rc;
     }
-    bool w_pending[3] = {false, false, false};
+    bool* w_pending = h->w_pending;
     bool slot_busy[2] = {false, false};
     // Where the HBM-bound slab reduces go: behind their GEMM on the side stream (default).  Measured alternatives:
     // CODAE_REDUCE_STREAM=main issues them on `s` one layer late (two alternating slab buffers) - no difference
@@ -392,7 +416,7 @@ int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi
         const bool to_dx = !chain && !step_mode && dx != nullptr;
         if (chain || to_dx) {
             // the buffer dgrad_l writes, (l-1)%3 == (l+2)%3, may still be read by wgrad_{l+2}
-            if (dual && !gemms_on_main && chain && w_pending[(l + 2) % 3] && l + 2 <= hi - 1) {
+            if (dual && !gemms_on_main && chain && w_pending[(l + 2) % 3]) {
                 CODAE_HIP_CHECK(hipStreamWaitEvent(s, h->ev_w[(l + 2) % 3], 0));
                 w_pending[(l + 2) % 3] = false;
             }
@@ -413,10 +437,8 @@ int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi
         if (rc) return rc;
     }
     if (dual) {
-        CODAE_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
-        CODAE_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join, 0));
-        CODAE_HIP_CHECK(hipEventRecord(h->ev_join2, h->side2));
-        CODAE_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join2, 0));
+        h->side_dirty = true;
+        if (join) return join_side(h, s);
     }
     return CODAE_OK;
 }
@@ -714,11 +736,31 @@ int codae_step_backward(codae_handle h, const codae_buffers* b, int32_t B, int32
     return backward_range(h, b, B, layer_lo, layer_hi, nullptr, true, (hipStream_t)stream);
 }
 
+int codae_step_backward_async(codae_handle h, const codae_buffers* b, int32_t B, int32_t layer_lo, int32_t layer_hi, void* stream) {
+    int rc = check_common(h, b, B);
+    if (rc) return rc;
+    CODAE_REQUIRE(b->grads && b->dacts, "codae_step_backward_async: grads / dacts missing");
+    CODAE_REQUIRE(layer_lo >= 0 && layer_lo < layer_hi && layer_hi <= h->L, "codae_step_backward_async: layer range [%d, %d)", layer_lo, layer_hi);
+    return backward_range(h, b, B, layer_lo, layer_hi, nullptr, true, (hipStream_t)stream, false);
+}
+
+int codae_side_stream(codae_handle h, void** out) {
+    CODAE_REQUIRE(h && out, "codae_side_stream: null argument");
+    *out = nullptr;
+    if (getenv("CODAE_SINGLE_STREAM") != nullptr) return CODAE_OK;      // everything runs on the caller's stream
+    int rc = ensure_side_stream(h);
+    if (rc) return rc;
+    *out = h->side;
+    return CODAE_OK;
+}
+
 static int update_impl(codae_handle h, const codae_buffers* b, const codae_hyper* hyper, hipStream_t s, bool weights_norm_done) {
     CODAE_REQUIRE(h && b && hyper, "codae_step_update: null argument");
     CODAE_REQUIRE(b->params && b->grads && b->adam_m && b->adam_v && b->scalars, "codae_step_update: buffer missing");
     {
         int rcw = wait_transposed(h, s);      // Adam rewrites shadow_w, which a pending transpose still reads
+        if (rcw) return rcw;
+        rcw = join_side(h, s);                // (a backward issued with codae_step_backward_async)
         if (rcw) return rcw;
     }
     if (hyper->max_grad_norm > 0.f) {
@@ -808,6 +850,8 @@ int codae_step_update(codae_handle h, const codae_buffers* b, const codae_hyper*
 int codae_join(codae_handle h, void* stream) {
     CODAE_REQUIRE(h != nullptr, "codae_join: null handle");
     int rc = wait_transposed(h, (hipStream_t)stream);
+    if (rc) return rc;
+    rc = join_side(h, (hipStream_t)stream);
     if (rc) return rc;
     return wait_all_params(h, (hipStream_t)stream);
 }

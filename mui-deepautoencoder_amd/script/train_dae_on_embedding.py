@@ -60,7 +60,8 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        from codae.train import init_rccl_process_group
+        init_rccl_process_group(device)
 
     log.info("Loading dataset.")
     dataset = load_dataset_of_embeddings(embedding_path=args.embedding_path, config=config, cache_dir="tmp/")
