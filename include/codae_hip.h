@@ -204,6 +204,9 @@ enum {
 int codae_profile_begin(codae_handle h, uint32_t class_mask, int32_t max_records);
 /* Stop recording, wait for the recorded events and return per record the class and the elapsed
  * milliseconds.  n_out receives the number of records written (<= capacity). */
+/* Time launches only in every n-th training step (default 1 = every step): an event pair costs 2-4 us of stream time,
+ * which matters when the region being timed is also the throughput measurement. */
+int codae_profile_stride(codae_handle h, int32_t every_n_steps);
 int codae_profile_end(codae_handle h, int32_t* kinds, float* ms, int32_t capacity, int32_t* n_out);
 
 /* ---- stand-alone ops (also used by the drop-in classes) ------------------- */

@@ -72,6 +72,7 @@ PROTOTYPES = {
     "codae_step_update": (C.c_int, [_P, C.POINTER(Buffers), C.POINTER(Hyper), _P]),
     "codae_step_backward_async": (C.c_int, [_P, C.POINTER(Buffers), _I32, _I32, _I32, _P]),
     "codae_side_stream": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
+    "codae_profile_stride": (C.c_int, [_P, _I32]),
     "codae_join": (C.c_int, [_P, _P]),
     "codae_train_step": (C.c_int, [_P, C.POINTER(Buffers), C.POINTER(Batch), C.POINTER(Hyper), _P]),
     "codae_eval_step": (C.c_int, [_P, C.POINTER(Buffers), C.POINTER(Batch), _P, _P]),

@@ -212,8 +212,9 @@ class DaeEngine:
         with torch.cuda.device(self.device):
             check(self._lib.codae_eval_step(self._h, C.byref(self.bufs), C.byref(batch), ptr(out_y), current_stream()))
 
-    def profile_begin(self, classes=("gemm_fwd", "gemm_dgrad", "gemm_wgrad"), max_records=4096):
+    def profile_begin(self, classes=("gemm_fwd", "gemm_dgrad", "gemm_wgrad"), max_records=4096, every=1):
         from . import KERNEL_CLASSES
+        check(self._lib.codae_profile_stride(self._h, int(every)))
         mask = 0
         for c in classes:
             mask |= 1 << KERNEL_CLASSES.index(c)

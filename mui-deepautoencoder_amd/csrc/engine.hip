@@ -61,6 +61,7 @@ struct codae_engine {
     mutable bool prof_on = false;
     mutable uint32_t prof_mask = 0;
     mutable int prof_n = 0;
+    mutable int prof_every = 1, prof_step = 0;   // launches are timed in every prof_every-th training step only
     mutable std::vector<hipEvent_t> prof_start, prof_stop;
     mutable std::vector<int> prof_kind;
     int esize() const { return prec == CODAE_PREC_BF16 ? 2 : 4; }
@@ -75,7 +76,8 @@ struct ProfScope {
     hipStream_t s;
     int slot = -1;
     ProfScope(const codae_engine* e_, int kind, hipStream_t s_) : e(e_), s(s_) {
-        if (e->prof_on && ((e->prof_mask >> kind) & 1u) && e->prof_n < (int)e->prof_start.size()) {
+        if (e->prof_on && ((e->prof_mask >> kind) & 1u) && (e->prof_step % e->prof_every) == 0 &&
+            e->prof_n < (int)e->prof_start.size()) {
             slot = e->prof_n++;
             e->prof_kind[slot] = kind;
             (void)hipEventRecord(e->prof_start[slot], s);
@@ -545,7 +547,13 @@ int codae_profile_begin(codae_handle h, uint32_t class_mask, int32_t max_records
         CODAE_HIP_CHECK(hipEventCreate(&h->prof_start[i]));
         CODAE_HIP_CHECK(hipEventCreate(&h->prof_stop[i]));
     }
-    h->prof_mask = class_mask; h->prof_n = 0; h->prof_on = true;
+    h->prof_mask = class_mask; h->prof_n = 0; h->prof_on = true; h->prof_step = 0;
+    return CODAE_OK;
+}
+
+int codae_profile_stride(codae_handle h, int32_t every_n_steps) {
+    CODAE_REQUIRE(h && every_n_steps >= 1, "codae_profile_stride: bad arguments");
+    h->prof_every = every_n_steps;
     return CODAE_OK;
 }
 
@@ -663,6 +671,7 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
     CODAE_REQUIRE(batch->io == h->in[0] && batch->io == h->out[h->L - 1], "batch.io %d does not match the model (%d -> %d)",
                   batch->io, h->in[0], h->out[h->L - 1]);
     CODAE_REQUIRE(b->grads && b->dacts && b->scalars, "codae_step_forward_loss: grads / dacts / scalars missing");
+    if (h->prof_on) ++h->prof_step;
     hipStream_t s = (hipStream_t)stream;
     const int B = batch->B, L = h->L;
     const int rows = h->rows_for(B);
