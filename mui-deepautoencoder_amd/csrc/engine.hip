@@ -26,6 +26,8 @@ using namespace codae;
 // Flat parameter layout: [W_0 | W_1 | ... | W_{L-1} | b_0 | ... | b_{L-1}], every tensor padded to
 // a multiple of 64 floats (256 B) so each starts 16-B aligned and the whole vector can be swept
 // 16 B per lane by the norm / Adam kernels.  Padding stays zero under Adam (g = 0, p = 0).
+constexpr int CODAE_MAX_DACT = 16;
+
 struct codae_engine {
     int L = 0;
     std::vector<int> in, out;
@@ -37,12 +39,13 @@ struct codae_engine {
     int maxw = 0;
     std::vector<int64_t> act_off;  // byte offsets of act[0..L-1] and y (index L) inside bufs->acts
     int64_t act_bytes = 0, dact_one = 0, slab_bytes = 0;
+    int n_dact = 3;          // rotating activation-gradient buffers: min(L + 1, CODAE_MAX_DACT)
     std::vector<int> split_k;
     // optional per-launch hipEvent pairs (codae_profile_begin / _end)
     // backward on two streams: the weight-gradient GEMMs (+ slab reduce) run on `side`, concurrently with
     // the data-gradient chain on the caller's stream (they only share the read-only dA_l)
     mutable hipStream_t side = nullptr, side2 = nullptr;   // side2: the HBM-bound slab reduces
-    mutable hipEvent_t ev_ready = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_w[3] = {nullptr, nullptr, nullptr};
+    mutable hipEvent_t ev_ready = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_w[CODAE_MAX_DACT] = {};
     mutable hipEvent_t ev_g[2] = {nullptr, nullptr}, ev_r[2] = {nullptr, nullptr};   // per slab buffer: GEMM done / reduce done
     // deferred Adam: layer l's parameters are updated on `side` beside the NEXT forward; forward layer l waits ev_adam[l]
     mutable hipEvent_t ev_adam[64] = {};
@@ -54,7 +57,7 @@ struct codae_engine {
     mutable bool wt_pending = false;
     // dA buffer i is still being read by a side-stream wgrad (event ev_w[i]); kept across calls so that a backward
     // issued bucket by bucket without joins (codae_step_backward_async) stays ordered
-    mutable bool w_pending[3] = {false, false, false};
+    mutable bool w_pending[CODAE_MAX_DACT] = {};
     mutable bool side_dirty = false;      // side-stream work not yet joined into the caller's stream
     // single-GPU fused step: the slab reduce of every layer also accumulates sum g^2 (clip_grad_norm_)
     mutable bool norm_in_backward = false;
@@ -117,7 +120,7 @@ inline void* act_ptr(const codae_engine* e, const codae_buffers* b, int l) {
     return reinterpret_cast<char*>(b->acts) + e->act_off[l];
 }
 inline void* dact_ptr(const codae_engine* e, const codae_buffers* b, int l) {
-    return reinterpret_cast<char*>(b->dacts) + (int64_t)(l % 3) * e->dact_one;   // 3 buffers: see backward_range
+    return reinterpret_cast<char*>(b->dacts) + (int64_t)(l % e->n_dact) * e->dact_one;   // see backward_range
 }
 
 int check_common(codae_handle h, const codae_buffers* b, int B) {
@@ -187,7 +190,7 @@ int run_wgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, hi
         g.ldc = K; g.c_f32 = 1; g.split_k = S;
         if (S > 1) {
             CODAE_REQUIRE(b->slabs != nullptr, "bf16 wgrad needs the slab workspace");
-            char* slab = reinterpret_cast<char*>(b->slabs) + (rs ? (int64_t)slot * e->slab_bytes : 0);
+            char* slab = reinterpret_cast<char*>(b->slabs) + (int64_t)slot * e->slab_bytes;   // (two slab buffers)
             g.C = slab;
             if (rs && slot_busy[slot]) {                   // this buffer's previous reduce must be done
                 CODAE_HIP_CHECK(hipStreamWaitEvent(s, e->ev_r[slot], 0));
@@ -332,7 +335,7 @@ int ensure_side_stream(const codae_engine* h) {
     }
     CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
     CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-    for (int i = 0; i < 3; ++i) CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_w[i], hipEventDisableTiming));
+    for (int i = 0; i < CODAE_MAX_DACT; ++i) CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_w[i], hipEventDisableTiming));
     CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_norm, hipEventDisableTiming));
     CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_wt_src, hipEventDisableTiming));
     CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_wt, hipEventDisableTiming));
@@ -347,7 +350,7 @@ int join_side(const codae_engine* h, hipStream_t s) {
     CODAE_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join, 0));
     CODAE_HIP_CHECK(hipEventRecord(h->ev_join2, h->side2));
     CODAE_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join2, 0));
-    for (int i = 0; i < 3; ++i) h->w_pending[i] = false;
+    for (int i = 0; i < CODAE_MAX_DACT; ++i) h->w_pending[i] = false;
     h->side_dirty = false;
     return CODAE_OK;
 }
@@ -399,6 +402,11 @@ int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi
             // every GEMM on `s` (no gaps, no CU sharing); only the HBM-bound slab reduce goes to the side stream
             rc = run_wgrad(h, b, l, rows, s, h->side, l & 1, slot_busy);
             if (rc) return rc;
+        } else if (dual && join && step_mode && l == 0 && hi - lo >= 3 && getenv("CODAE_TAIL_ON_SIDE") == nullptr) {
+            // tail: the side stream still owes wgrad_1 when the dgrad chain ends, and the caller's stream has
+            // nothing left to do: the last weight gradient runs here (third slab buffer), beside wgrad_1
+            rc = run_wgrad(h, b, l, rows, s, nullptr, 2);
+            if (rc) return rc;
         } else if (dual) {
             CODAE_HIP_CHECK(hipEventRecord(h->ev_ready, s));                // dA_l (and act[l]) are complete on s
             CODAE_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_ready, 0));
@@ -408,8 +416,10 @@ int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi
                 rc = run_wgrad(h, b, l, rows, h->side, (reduce_stream || (rmode && rmode[0] == 't')) ? h->side2 : nullptr,
                                l & 1, slot_busy);
             if (rc) return rc;
-            CODAE_HIP_CHECK(hipEventRecord(h->ev_w[l % 3], h->side));
-            w_pending[l % 3] = true;
+            if (h->n_dact <= h->L) {            // (with a buffer per layer nothing is ever overwritten within a step)
+                CODAE_HIP_CHECK(hipEventRecord(h->ev_w[l % h->n_dact], h->side));
+                w_pending[l % h->n_dact] = true;
+            }
         } else {
             rc = run_wgrad(h, b, l, rows, s);
             if (rc) return rc;
@@ -417,10 +427,11 @@ int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi
         const bool chain = step_mode ? (l > 0) : (l > lo);
         const bool to_dx = !chain && !step_mode && dx != nullptr;
         if (chain || to_dx) {
-            // the buffer dgrad_l writes, (l-1)%3 == (l+2)%3, may still be read by wgrad_{l+2}
-            if (dual && !gemms_on_main && chain && w_pending[(l + 2) % 3]) {
-                CODAE_HIP_CHECK(hipStreamWaitEvent(s, h->ev_w[(l + 2) % 3], 0));
-                w_pending[(l + 2) % 3] = false;
+            // the buffer dgrad_l writes, (l-1) % n, was last read by wgrad_{l-1+n}
+            const int wb = (l - 1 + h->n_dact) % h->n_dact;
+            if (dual && !gemms_on_main && chain && w_pending[wb]) {
+                CODAE_HIP_CHECK(hipStreamWaitEvent(s, h->ev_w[wb], 0));
+                w_pending[wb] = false;
             }
             rc = chain ? run_dgrad(h, b, l, rows, nullptr, s) : run_dgrad(h, b, l, B, dx, s);
             if (rc) return rc;
@@ -500,6 +511,10 @@ int codae_create(const codae_spec* spec, codae_handle* out) {
     a += round_up((int64_t)e->max_rows * e->out[e->L - 1] * 4, 256);
     e->act_bytes = a;
     e->dact_one = round_up((int64_t)e->max_rows * e->maxw * e->esize(), 256);
+    // one activation-gradient buffer per layer when the stack is shallow enough (no write-after-read waits between the
+    // two backward streams, whose barrier packets cost ~11 us each); deeper stacks rotate through CODAE_MAX_DACT
+    e->n_dact = e->L + 1 <= CODAE_MAX_DACT ? e->L + 1 : CODAE_MAX_DACT;
+    if (e->n_dact < 3) e->n_dact = 3;
     e->slab_bytes = 0;
     for (int l = 0; l < e->L; ++l) {
         int s = 1;
@@ -526,7 +541,7 @@ int codae_destroy(codae_handle h) {
     if (h && h->side) {
         (void)hipStreamSynchronize(h->side);
         (void)hipEventDestroy(h->ev_ready); (void)hipEventDestroy(h->ev_join);
-        for (int i = 0; i < 3; ++i) (void)hipEventDestroy(h->ev_w[i]);
+        for (int i = 0; i < CODAE_MAX_DACT; ++i) (void)hipEventDestroy(h->ev_w[i]);
         (void)hipStreamSynchronize(h->side2);
         (void)hipEventDestroy(h->ev_norm);
         (void)hipEventDestroy(h->ev_wt_src); (void)hipEventDestroy(h->ev_wt);
@@ -577,8 +592,8 @@ int codae_get_sizes(codae_handle h, codae_sizes* out) {
     out->n_param = h->n_param;
     out->n_weight = h->prec == CODAE_PREC_BF16 ? h->n_param : 0;
     out->act_bytes = h->act_bytes;
-    out->dact_bytes = 3 * h->dact_one;
-    out->slab_bytes = 2 * h->slab_bytes;   // two alternating slab buffers (reduce of layer l under the GEMM of l-1)
+    out->dact_bytes = h->n_dact * h->dact_one;
+    out->slab_bytes = 3 * h->slab_bytes;   // side stream: two alternating slab buffers; caller's stream (tail wgrad): the third
     out->n_scalars = CODAE_S_COUNT;
     return CODAE_OK;
 }
