@@ -340,3 +340,50 @@ def test_fused_loss_epilogue_matches_separate_loss_kernel(monkeypatch, S, E, B):
         assert abs(a[k] - b[k]) <= 2e-3 * abs(b[k]), (k, a[k], b[k])
     assert np.allclose(a[4], b[4], rtol=2e-2, atol=1e-7)          # last-layer bias gradient
     assert np.allclose(a[5], b[5], rtol=5e-2, atol=2e-6)          # first-layer weight gradient (through the whole chain)
+
+
+def test_full_size_c3_gradient_is_additive_over_row_shards():
+    """BASELINE config C3 (10 x Linear(1536,1536), batch 8192, bf16) through a size-independent property: with the loss
+    scaled by the GLOBAL batch, grad(full batch) = grad(first half) + grad(second half) — what the data-parallel
+    sharding relies on.  Rows are independent in the forward, so the only differences are fp32 summation order in the
+    weight-gradient GEMM (split-K ranges move) and the atomics of the bias sums.  Also: the bucketed no-join backward
+    (codae_step_backward_async) must give the joined backward's gradients exactly (weights) / to atomics order (biases)."""
+    from codae.hip.engine import DaeEngine
+    S, E, B, L = 3, 512, 8192, 10
+    io = S * E
+    g = torch.Generator(device="cpu").manual_seed(21)
+    relu = [True] * 4 + [False] + [True] * 4 + [False]
+    eng = DaeEngine([(io, io, r) for r in relu], B, "bf16", DEV)
+    lim = (6.0 / (2 * io)) ** 0.5
+    eng.load_params([((torch.rand(io, io, generator=g) * 2 - 1) * lim, torch.zeros(io)) for _ in range(L)])
+    data = torch.rand(B + 64, io, generator=g).to(DEV)
+    table = torch.ones(S, io, dtype=torch.uint8)
+    for s in range(S):
+        table[s, s * E:(s + 1) * E] = 0
+    table = table.to(DEV)
+    mask_id = torch.randint(0, S, (B,), generator=g, dtype=torch.int32).to(DEV)
+    rows = torch.randperm(B + 64, generator=g)[:B].to(torch.int32).to(DEV)
+    hyper = eng.hyper(1e-5, 1e-4, clip=1.0, global_rows=B)
+
+    def grads_of(lo, hi, buckets=None):
+        batch = eng.make_batch(data, rows[lo:hi].contiguous(), mask_id[lo:hi].contiguous(), table)
+        eng.step_forward_loss(batch, hyper)
+        if buckets is None:
+            eng.step_backward(hi - lo, 0, L)
+        else:
+            for blo, bhi in buckets:
+                eng.step_backward(hi - lo, blo, bhi, join=False)
+            eng.join()
+        torch.cuda.synchronize()
+        return eng.grads.clone()
+
+    full = grads_of(0, B)
+    nw = eng.b_off[0]                                   # weights first, then the bias block
+    assert float(full[:nw].abs().max()) > 0 and bool(torch.isfinite(full).all())
+    bucketed = grads_of(0, B, buckets=[(6, 10), (3, 6), (1, 3), (0, 1)])
+    assert torch.equal(full[:nw], bucketed[:nw])
+    assert torch.allclose(full[nw:], bucketed[nw:], rtol=0, atol=1e-6)
+    halves = grads_of(0, B // 2) + grads_of(B // 2, B)
+    scale = float(full[:nw].abs().max())
+    assert float((full[:nw] - halves[:nw]).abs().max()) <= 2e-3 * scale
+    assert float((full[nw:] - halves[nw:]).abs().max()) <= 2e-3 * float(full[nw:].abs().max())
