@@ -227,12 +227,13 @@ def main():
     barrier()
     kernel_events = not args.no_kernel_events
     if kernel_events:
-        # hipEvent pairs cost 2-4 us per launch INSIDE the timed region (they break back-to-back dispatch): by
-        # default only the kernel the roofline is quoted on is timed, in every 4th step of the timed region (~1 % of
-        # the region instead of ~5 % for all its launches);
-        # --all-kernel-events adds the other GEMM classes (30 launches per step: ~10 % slower steps)
+        # A hipEvent pair costs 2-4 us of stream time INSIDE the timed region (it breaks back-to-back dispatch).  The
+        # forward launches of a step (the class the roofline is quoted on) are dependent, gap-free kernels on one
+        # stream, so the engine brackets the whole run of them with ONE pair and reports elapsed / launches:
+        # ~0.3 % of the step.  --all-kernel-events adds per-launch pairs for the other classes (20 more pairs per
+        # step: ~8 % slower steps).
         classes = ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "loss") if args.all_kernel_events else ("gemm_fwd",)
-        tr.engine.profile_begin(classes, max_records=32 * args.steps + 64, every=1 if args.all_kernel_events else 4)
+        tr.engine.profile_begin(classes, max_records=32 * args.steps + 64, every=1)
     t0 = time.perf_counter()
     for st in range(args.warmup, total_steps):
         tr.train_batch(idx_steps[st], run=0)
@@ -269,7 +270,7 @@ def main():
         roof = None
         if prof:
             by = {}
-            sampled_steps = args.steps if args.all_kernel_events else args.steps // 4
+            sampled_steps = args.steps
             gemm_flops = 2.0 * B * io * io
             for name, ms in prof.items():
                 mean_ms = float(np.mean(ms))
