@@ -1,0 +1,66 @@
+"""profiles/hbm_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py.
+
+Usage: python tools/hbm_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [out.json]
+bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (MI355X_MICROARCH.md, HBM section: FETCH_SIZE / WRITE_SIZE are
+in KiB and, on gfx950, FETCH_SIZE tallies the 128-B requests of wide coalesced reads at 64 B)."""
+import csv, json, sys, collections
+
+
+def per_kernel(path, counter):
+    acc = collections.defaultdict(list)
+    per_dispatch = collections.defaultdict(float)
+    names = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        key = r["Dispatch_Id"]
+        per_dispatch[key] += float(r["Counter_Value"])      # summed over XCDs / instances
+        names[key] = r["Kernel_Name"]
+    for k, v in per_dispatch.items():
+        acc[names[k]].append(v)
+    return {n: sum(v) / len(v) for n, v in acc.items()}, {n: len(v) for n, v in acc.items()}
+
+
+def classify(name):
+    if "gemm_bf16_pipe_kernel" in name:
+        args = name[name.index("<") + 1:name.index(">")].replace(" ", "").split(",")
+        a_mode, b_mode, c_f32, epi = args[5], args[6], args[7], args[9] if len(args) > 9 else "0"
+        if c_f32 == "true":
+            return "gemm_wgrad"
+        return "gemm_dgrad" if epi == "2" else "gemm_fwd"
+    if "gemm_bf16_kernel" in name and name.replace(" ", "").endswith("true>(codae::GemmBf16,int,int,int)"):
+        return "loss_gemm"
+    for key, cls in (("clip_adam", "adam"), ("reduce_slabs", "slab_reduce"), ("gather_corrupt", "gather"),
+                     ("transpose_bf16", "transpose"), ("cast_bf16", "cast_bf16")):
+        if key in name:
+            return cls
+    return None
+
+
+def main():
+    fetch, nf = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write, _ = per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for name, f in fetch.items():
+        cls = classify(name)
+        if cls is None:
+            continue
+        w = write.get(name, 0.0)
+        out[cls] = {"bytes_per_launch": (2.0 * f + w) * 1024.0, "read": 2.0 * f * 1024.0, "written": w * 1024.0,
+                    "launches_sampled": nf[name]}
+    res = {k: v["bytes_per_launch"] for k, v in out.items() if k.startswith("gemm_")}
+    res["_detail"] = out
+    res["_unit"] = ("bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts half of wide "
+                    "coalesced reads; MI355X_MICROARCH.md, HBM section); fabric traffic of the XCD L2s, Infinity-Cache "
+                    "hits included")
+    res["_algorithmic"] = {"gemm_fwd": 55.1e6, "gemm_dgrad": 80.3e6, "gemm_wgrad": 97.5e6}
+    res["_source"] = "tools/hbm_traffic.py %s %s" % (sys.argv[1].split("/")[-1], sys.argv[2].split("/")[-1])
+    path = sys.argv[3] if len(sys.argv) > 3 else "profiles/hbm_traffic.json"
+    json.dump(res, open(path, "w"), indent=1)
+    for k, v in sorted(out.items()):
+        print("%-12s %8.1f MB per launch (read %7.1f, written %7.1f; %d launches)" %
+              (k, v["bytes_per_launch"] / 1e6, v["read"] / 1e6, v["written"] / 1e6, v["launches_sampled"]))
+
+
+if __name__ == "__main__":
+    main()
