@@ -459,33 +459,52 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
         }
         return;
     }
-    // fp32 output (split-K slabs / fp32 y): 16 B per lane straight from the accumulators
-    char* Cbase = reinterpret_cast<char*>(g.C);
-    if (g.split_k > 1) Cbase += (int64_t)z * g.M * g.ldc * sizeof(float);
+    // fp32 output (split-K slabs of the weight gradient, fp32 y): staged through LDS like the bf16 path, in the two
+    // row halves of the phase structure (the fp32 tile is twice the staging space); whole 768-B row segments,
+    // 16 B per lane.  (Straight from the accumulators a wave-store wrote 64-B pieces: the slab launch moved 60 MB
+    // for 47 MB of slabs.)
+    if constexpr (C_F32) {
+        constexpr int NT = 64 * NW;
+        constexpr int HR = AHR;
+        constexpr int PITCH = BN * 4 + 16;
+        static_assert(HR * PITCH <= 2 * BUF, "fp32 half tile must fit in the staging buffers");
+        constexpr int CH = BN / 4, RL = NT / CH;          // float4 chunks per row, rows per pass
+        float* Cf = reinterpret_cast<float*>(g.C);
+        if (g.split_k > 1) Cf += (int64_t)z * g.M * g.ldc;
+        const float floor_v = g.relu ? 0.f : -__builtin_inff();
+        const int c = threadIdx.x % CH, rl = threadIdx.x / CH;
+        const int j = j0 + c * 4;
 #pragma unroll
-    for (int nh = 0; nh < 2; ++nh)
+        for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
-        for (int nt = 0; nt < TNH; ++nt) {
-            const int j = j0 + nh * BHR + wc * (SN / 2) + 16 * nt + g4;
-            const bool jok = j < g.N;
-            float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g.bias != nullptr && jok) bj = *reinterpret_cast<const float4*>(g.bias + j);
+            for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-            for (int mh = 0; mh < 2; ++mh)
+                for (int nt = 0; nt < TNH; ++nt) {
+                    const int jl = nh * BHR + wc * (SN / 2) + 16 * nt + g4;
+                    float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (g.bias != nullptr && j0 + jl < g.N) bj = *reinterpret_cast<const float4*>(g.bias + j0 + jl);
 #pragma unroll
-                for (int mt = 0; mt < TMH; ++mt) {
-                    const int i = i0 + mh * AHR + wr * (SM / 2) + 16 * mt + li;
-                    if (i < g.M && jok && !dbg_nostore) {
-                        const f32x4 a = acc[mh][mt][nh][nt];
-                        float v0 = a[0] + bj.x, v1 = a[1] + bj.y, v2 = a[2] + bj.z, v3 = a[3] + bj.w;
-                        if (g.relu) {
-                            v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-                        }
-                        if constexpr (C_F32)
-                            *reinterpret_cast<float4*>(Cbase + ((int64_t)i * g.ldc + j) * 4) = make_float4(v0, v1, v2, v3);
+                    for (int mt = 0; mt < TMH; ++mt) {
+                        const int il = wr * (SM / 2) + 16 * mt + li;          // row inside this half
+                        const f32x4 a = acc[hh][mt][nh][nt];
+                        f32x4 v;
+                        v[0] = clamp_below(a[0] + bj.x, floor_v); v[1] = clamp_below(a[1] + bj.y, floor_v);
+                        v[2] = clamp_below(a[2] + bj.z, floor_v); v[3] = clamp_below(a[3] + bj.w, floor_v);
+                        *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(smem + il * PITCH + jl * 4) = v;
                     }
                 }
+            __syncthreads();
+            if (rl < RL && j < g.N) {
+                for (int r = rl; r < HR; r += RL) {
+                    const int i = i0 + hh * HR + r;
+                    if (i >= g.M) break;
+                    const f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(smem + r * PITCH + c * 16);
+                    *reinterpret_cast<float4*>(Cf + (int64_t)i * g.ldc + j) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+            __syncthreads();
         }
+    }
 }
 
 template <int BM, int BN, int WM, int WN, int NLB>
