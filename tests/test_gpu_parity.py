@@ -387,3 +387,44 @@ def test_full_size_c3_gradient_is_additive_over_row_shards():
     scale = float(full[:nw].abs().max())
     assert float((full[:nw] - halves[:nw]).abs().max()) <= 2e-3 * scale
     assert float((full[nw:] - halves[nw:]).abs().max()) <= 2e-3 * float(full[nw:].abs().max())
+
+
+def test_two_stream_step_matches_single_stream_over_many_steps(monkeypatch):
+    """Race check for the step's stream choreography (backward on two streams, per-layer dA buffers, alternating slab
+    buffers, tail wgrad on the caller's stream, transposed shadow refreshed on the side stream): 40 steps at a size that
+    takes the big-tile kernels must track the same run with everything on ONE stream (CODAE_SINGLE_STREAM=1, where no
+    ordering can go wrong).  The two differ only by float-atomics order in the bias sums, which Adam turns into
+    +-lr flips of near-zero-gradient parameters: the loss curves agree to 1e-3 (measured 1e-4), a race gives gross errors."""
+    from codae.train import HipEmbeddingTrainer
+    from oracle import dae_oracle as O
+    S, E, B, steps = 3, 256, 4096, 40
+    io = S * E
+    rng = np.random.default_rng(77)
+    N = 2 * B
+    data = rng.random((N, io), dtype=np.float32)
+    sched = O.layer_schedule(io, io, 2, 2, False, "embedding")
+    params = O.init_params(sched, rng)
+    bm, _, _ = O.corrupter_tables([{"size": E, "position": s * E} for s in range(S)], 1)
+    mtu = rng.integers(0, S, (N, 1)).astype(np.int32)
+    order = [torch.tensor(rng.permutation(N)[:B], dtype=torch.int32, device=DEV) for _ in range(steps)]
+    runs = []
+    for single in (True, False):
+        if single:
+            monkeypatch.setenv("CODAE_SINGLE_STREAM", "1")
+        else:
+            monkeypatch.delenv("CODAE_SINGLE_STREAM", raising=False)
+        tr = HipEmbeddingTrainer(sched, torch.tensor(data), torch.tensor(bm).to(torch.uint8), torch.tensor(mtu), 1e-3, 1e-4, 1.0,
+                                 max_batch=B, precision="bf16", device=DEV)
+        tr.load_params(params)
+        losses = []
+        for s in range(steps):
+            tr.train_batch(order[s], run=0)          # no host sync inside the loop: the streams run ahead freely
+            if s % 8 == 7 or s == steps - 1:
+                losses.append(tr.engine.read_scalars()[3])
+        runs.append((losses, tr.engine.params.clone()))
+    (la, pa), (lb, pb) = runs
+    assert la[-1] < la[0]                                    # it trains
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 1e-3 * abs(x), (la, lb)
+    d = (pa - pb).abs()
+    assert float(d.max()) <= 2 * 1e-3 * steps and float(d.mean()) <= 1e-3, (float(d.max()), float(d.mean()))
