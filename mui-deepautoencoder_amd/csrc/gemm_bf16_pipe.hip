@@ -32,6 +32,7 @@
 //   256 x 192 (2 x 2 waves, 128 x 96 per wave, a = 4, b = 3): 8192 x 1536 outputs = 256 workgroups
 //   256 x 256 (2 x 2 waves, 128 x 128 per wave, a = b = 4)
 #include "codae_common.h"
+#include <type_traits>
 
 namespace codae {
 namespace {
@@ -50,9 +51,12 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// every LDS read of this wave has returned; then the workgroup barrier
+// All but the wave's KEEP youngest LDS reads have returned; then the workgroup barrier.  The LDS-DMA issued after
+// the barrier overwrites a region whose last readers ran TWO phases ago, so the reads of the phase just finished
+// (KEEP of them, compiler-visible ds_read_b128 only) may stay in flight across it.
+template <int KEEP = 0>
 __device__ __forceinline__ void phase_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(KEEP) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
@@ -195,8 +199,12 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
     constexpr int BUF = 2 * AH + 2 * BH;
     // LDS-DMA instructions per wave per half-tile; the B half-tile may be loaded by the first NLB
     // waves only (256 x 192 with 8 waves: 12 instructions = 6 waves x 2), the others issue none
-    constexpr int NA = AHR / 8 / NW, NB = BHR / 8 / NLB;
-    static_assert(NLB <= NW, "loader waves");
+    // (likewise the A half-tile by the first NLA waves when its pieces do not divide over all of them.  A 12-wave
+    // form - 4 x 3 waves of 64 x 64, three per SIMD, 150 VGPRs - was measured: forward 36.2 vs 36.1 us for 8 waves,
+    // wgrad 54.6 vs 50.7: occupancy is not what limits the K loop; it is not instantiated)
+    constexpr int NLA = ((AHR / 8) % NW == 0) ? NW : 8;
+    constexpr int NA = AHR / 8 / NLA, NB = BHR / 8 / NLB;
+    static_assert(NLB <= NW && NLA <= NW && (AHR / 8) % NLA == 0 && (BHR / 8) % NLB == 0, "loader waves");
     static_assert(SM % 32 == 0 && SN % 32 == 0, "wave sub-tile must split into 16-wide half tiles");
     __shared__ __attribute__((aligned(16))) char smem_raw[2 * BUF];
     lds_char* smem = (lds_char*)smem_raw;
@@ -238,12 +246,13 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
     }
     // per-lane LDS-DMA source pointers at k = 0 (loop invariant) and the per-K-tile advance
     const bool b_loader = (NLB == NW) || (w < NLB);
+    const bool a_loader = (NLA == NW) || (w < NLA);
     const bf16_t* a_src[2][NA];
     const bf16_t* b_src[2][NB];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int it = 0; it < NA; ++it) a_src[h][it] = half_src<A_MODE, AHR, SM, NW>(g.A, g.lda, i0, g.M, h, it, w, lane) + (A_MODE == OP_KC ? (int64_t)kt_begin * BK : (int64_t)kt_begin * BK * g.lda);
+        for (int it = 0; it < NA; ++it) a_src[h][it] = half_src<A_MODE, AHR, SM, NLA>(g.A, g.lda, i0, g.M, h, it, a_loader ? w : 0, lane) + (A_MODE == OP_KC ? (int64_t)kt_begin * BK : (int64_t)kt_begin * BK * g.lda);
 #pragma unroll
         for (int it = 0; it < NB; ++it) b_src[h][it] = half_src<B_MODE, BHR, SN, NLB>(g.B, g.ldb, j0, g.N, h, it, b_loader ? w : 0, lane) + (B_MODE == OP_KC ? (int64_t)kt_begin * BK : (int64_t)kt_begin * BK * g.ldb);
     }
@@ -254,10 +263,12 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
     // and the vmcnt arithmetic is exact to the end (cost: ~2 extra K-tiles of L2-hit DMA per workgroup).
     auto issue_a = [&](int tile, int h) {
         if constexpr (!dbg_noload) {
-            const int64_t adv = (int64_t)(tile < nkt ? tile : nkt - 1) * a_step;
-            lds_char* img = a_img(tile, h);
+            if (a_loader) {
+                const int64_t adv = (int64_t)(tile < nkt ? tile : nkt - 1) * a_step;
+                lds_char* img = a_img(tile, h);
 #pragma unroll
-            for (int it = 0; it < NA; ++it) glds16(a_src[h][it] + adv, img + (it * NW + w) * 1024);
+                for (int it = 0; it < NA; ++it) glds16(a_src[h][it] + adv, img + (it * NLA + w) * 1024);
+            }
         }
     };
     auto issue_b = [&](int tile, int h) {
@@ -315,61 +326,70 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
                 for (int nt = 0; nt < TNH; ++nt)
                     acc[mh][mt][nh][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nt][s], a[mt][s], acc[mh][mt][nh][nt], 0, 0, 0);
     };
-    // the half this phase reads has landed once at most the 6 half-tiles issued after it are in flight
-    auto wait_half = [&]() {
-        if (NLB == NW || w < NLB) wait_vmcnt<3 * NA + 3 * NB>(); else wait_vmcnt<3 * NA>();
+    // LDS-DMA runs 6 phases ahead: the half-tile a phase reads has landed once at most the 5 half-tiles issued after
+    // it are in flight - 2 A + 3 B in the phases that read an A half (P1, P3), 3 A + 2 B in those that read a B half
+    // own LDS-DMA pieces that may still be in flight: CA A-halves + CB B-halves (per loader class of this wave)
+    auto wait_dma = [&](auto ca, auto cb) {
+        constexpr int CA = decltype(ca)::value, CB = decltype(cb)::value;
+        if (a_loader && b_loader) wait_vmcnt<CA * NA + CB * NB>();
+        else if (a_loader) wait_vmcnt<CA * NA>();
+        else if (b_loader) wait_vmcnt<CB * NB>();
     };
+    auto wait_for_a = [&]() { wait_dma(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}); };
+    auto wait_for_b = [&]() { wait_dma(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{}); };
 
-    // prologue = phases P3(-1), P4(-1) without MFMAs
+    // prologue: both K-tiles of the LDS ring are requested, then A0(0) and B0(0) are read
     issue_a(0, 0); issue_b(0, 0); issue_a(0, 1); issue_b(0, 1);
-    issue_a(1, 0); issue_b(1, 0); issue_a(1, 1);
-    wait_half();
+    issue_a(1, 0); issue_b(1, 0); issue_a(1, 1); issue_b(1, 1);
+    wait_dma(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{});      // A0(0) landed
     phase_barrier();
-    issue_b(1, 1);
     read_a(a0x, 0, 0);
-    wait_half();
+    wait_dma(std::integral_constant<int, 3>{}, std::integral_constant<int, 3>{});      // B0(0) landed
     phase_barrier();
-    issue_a(2, 0);
     read_b(b0, 0, 0);
 
     stamp(1);
     constexpr int N_MMA = 2 * TMH * TNH;
     constexpr int RD_A = 2 * TMH * (A_MODE == OP_KC ? 1 : 2), RD_B = 2 * TNH * (B_MODE == OP_KC ? 1 : 2);
+    // reads that may stay in flight across the barrier after a phase that read an A / a B half: the compiler-visible
+    // ds_read_b128 of a k-contiguous operand (it waits for them itself before their first use); the asm-issued
+    // transposed reads of a k-strided operand are waited for in full (settle() follows the barrier)
+    constexpr int KEEP_A = A_MODE == OP_KC ? 2 * TMH : 0, KEEP_B = B_MODE == OP_KC ? 2 * TNH : 0;
     // one K-tile; `a0` holds A0(t), `a0n` receives A0(t+1).  Reads of a tile past the end fetch the
     // dummy re-load and are never multiplied.
     auto ktile = [&](int t, bf16x8 (&a0)[TMH][2], bf16x8 (&a0n)[TMH][2]) {
         // P1: A0 x B0
-        wait_half();
-        phase_barrier();
+        wait_for_a();
+        phase_barrier<KEEP_B>();            // (the previous phase, P4, read a B half)
         if constexpr (A_MODE == OP_KS) settle(a0);
         if constexpr (B_MODE == OP_KS) settle(b0);
-        issue_b(t + 2, 0);
+        issue_a(t + 2, 0);
         read_a(a1, t, 1);
         mma(a0, b0, 0, 0);
-        if constexpr (NW == 4) interleave<N_MMA, RD_A, NB>();
+        if constexpr (NW == 4) interleave<N_MMA, RD_A, NA>();
         // P2: A1 x B0
-        wait_half();
-        phase_barrier();
+        wait_for_b();
+        phase_barrier<KEEP_A>();
         if constexpr (A_MODE == OP_KS) settle(a1);
-        issue_a(t + 2, 1);
+        issue_b(t + 2, 0);
         read_b(b1, t, 1);
         mma(a1, b0, 1, 0);
-        if constexpr (NW == 4) interleave<N_MMA, RD_B, NA>();
+        if constexpr (NW == 4) interleave<N_MMA, RD_B, NB>();
         // P3: A1 x B1
-        wait_half();
-        phase_barrier();
+        wait_for_a();
+        phase_barrier<KEEP_B>();
         if constexpr (B_MODE == OP_KS) settle(b1);
-        issue_b(t + 2, 1);
+        issue_a(t + 2, 1);
         read_a(a0n, t + 1, 0);
         mma(a1, b1, 1, 1);
-        if constexpr (NW == 4) interleave<N_MMA, RD_A, NB>();
+        if constexpr (NW == 4) interleave<N_MMA, RD_A, NA>();
         // P4: A0 x B1
-        wait_half();
-        phase_barrier();
-        issue_a(t + 3, 0);
+        wait_for_b();
+        phase_barrier<KEEP_A>();
+        issue_b(t + 2, 1);
         read_b(b0, t + 1, 0);
         mma(a0, b1, 0, 1);
-        if constexpr (NW == 4) interleave<N_MMA, RD_B, NA>();
+        if constexpr (NW == 4) interleave<N_MMA, RD_B, NB>();
     };
     int t = 0;
     for (; t + 1 < nkt; t += 2) {
@@ -557,6 +577,8 @@ int gemm_bf16_pipe(const GemmBf16& g, int cfg, hipStream_t s) {
             case 6: return launch_dbg<6>(g, s);
             case 7: return launch_dbg<7>(g, s);
             case 8: return launch_dbg<8>(g, s);
+            case 9: return launch_dbg<9>(g, s);      // stamps + no LDS-DMA
+            case 10: return launch_dbg<10>(g, s);    // stamps + no MFMA
             default: break;
         }
     }

@@ -9,7 +9,7 @@ from codae import hip
 L = hip.lib()
 M, N = 8192, 1536
 dev = torch.device("cuda:0")
-os.environ["CODAE_GEMM_DBG"] = "8"
+os.environ["CODAE_GEMM_DBG"] = os.environ.get("TIMELINE_DBG", "8")   # 9: + no LDS-DMA, 10: + no MFMA (ablations)
 os.environ["CODAE_GEMM_DBG8"] = "1"
 g = torch.Generator(device="cpu").manual_seed(0)
 st = hip.current_stream()
