@@ -155,6 +155,7 @@ def main():
                     help="do not record per-launch hipEvents in the timed region (roofline then null)")
     ap.add_argument("--buckets", type=int, default=4)
     ap.add_argument("--all-kernel-events", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (single GPU; no live kernel events)")
     args = ap.parse_args()
 
     import numpy as np
@@ -200,7 +201,7 @@ def main():
 
     tr = HipEmbeddingTrainer(schedule, torch.from_numpy(data), torch.from_numpy(table), mask_to_use, LR, WD, CLIP,
                              max_batch=B, precision=args.precision, device=dev, distributed=distributed,
-                             n_buckets=args.buckets)
+                             n_buckets=args.buckets, use_graph=args.graph and not distributed)
     tr.init_params(seed=0)
 
     # per-step row indices, resident before timing: one permutation of the dataset per epoch, the
@@ -225,7 +226,7 @@ def main():
     for st in range(args.warmup):
         tr.train_batch(idx_steps[st], run=0)
     barrier()
-    kernel_events = not args.no_kernel_events
+    kernel_events = not args.no_kernel_events and not args.graph
     if kernel_events:
         # A hipEvent pair costs 2-4 us of stream time INSIDE the timed region (it breaks back-to-back dispatch).  The
         # forward launches of a step (the class the roofline is quoted on) are dependent, gap-free kernels on one

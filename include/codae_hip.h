@@ -98,7 +98,8 @@ enum {
     CODAE_S_GRAD_SQ_SLOTS = 8, /* 64 partial sums of g^2: same-address atomics serialise (~12 ns each), so
                                   reduction kernels scatter over these slots; sum g^2 = GRAD_SQ + sum(slots) */
     CODAE_S_N_SLOTS = 64,
-    CODAE_S_COUNT = 72
+    CODAE_S_ADAM_STEP = 72,  /* graph replay: Adam's step count t, written before each codae_train_step_graph launch */
+    CODAE_S_COUNT = 80
 };
 
 /* One minibatch of the hot loop (train_dae_on_embedding.py:194-203). */
@@ -166,6 +167,14 @@ int codae_step_update(codae_handle h, const codae_buffers* bufs, const codae_hyp
 /* Make `stream` wait for everything the engine still has in flight on its own streams (the per-layer Adam
  * kernels of the last update run beside the next forward).  Call before reading parameters, Adam state or
  * gradients from another stream / the host. */
+/* codae_train_step replayed from a hipGraph: the first call (and any call whose batch shape / pointers / hyper-
+ * parameters differ from the captured ones) captures the whole step - both streams of the backward included - and
+ * instantiates it; every call then costs one scalar write (Adam's step count, kept in device memory because kernel
+ * arguments are frozen at capture) and one hipGraphLaunch instead of ~55 kernel launches.  For launch-bound shapes
+ * (small batches: the reference's stock BATCH_SIZE 128).  batch->row_idx / mask_id must point to buffers whose
+ * CONTENTS the caller refreshes between calls (same addresses).  Same results as codae_train_step. */
+int codae_train_step_graph(codae_handle h, const codae_buffers* bufs, const codae_batch* batch,
+                           const codae_hyper* hyper, void* stream);
 /* Data-parallel form of codae_step_backward: returns WITHOUT making `stream` wait for the engine's side stream.
  * When it returns, the weight gradients of [layer_lo, layer_hi) are complete in enqueue order on the stream
  * codae_side_stream() reports (on `stream` itself when that is NULL), the bias and data gradients on `stream`.

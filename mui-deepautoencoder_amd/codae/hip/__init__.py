@@ -75,6 +75,7 @@ PROTOTYPES = {
     "codae_profile_stride": (C.c_int, [_P, _I32]),
     "codae_join": (C.c_int, [_P, _P]),
     "codae_train_step": (C.c_int, [_P, C.POINTER(Buffers), C.POINTER(Batch), C.POINTER(Hyper), _P]),
+    "codae_train_step_graph": (C.c_int, [_P, C.POINTER(Buffers), C.POINTER(Batch), C.POINTER(Hyper), _P]),
     "codae_eval_step": (C.c_int, [_P, C.POINTER(Buffers), C.POINTER(Batch), _P, _P]),
     "codae_profile_begin": (C.c_int, [_P, C.c_uint32, _I32]),
     "codae_profile_end": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_float), _I32, C.POINTER(C.c_int32)]),

@@ -176,10 +176,12 @@ class DaeEngine:
         return Hyper(lr, weight_decay, betas[0], betas[1], eps, clip if clip else 0.0,
                      self.step_count + 1 if step is None else step, float(global_rows))
 
-    def train_step(self, batch, hyper):
+    def train_step(self, batch, hyper, graph=False):
+        """graph=True: replay the step from a hipGraph (captured on first use; batch.row_idx / mask_id must be
+        buffers whose contents, not addresses, change between calls)."""
+        fn = self._lib.codae_train_step_graph if graph else self._lib.codae_train_step
         with torch.cuda.device(self.device):
-            check(self._lib.codae_train_step(self._h, C.byref(self.bufs), C.byref(batch), C.byref(hyper),
-                                             current_stream()))
+            check(fn(self._h, C.byref(self.bufs), C.byref(batch), C.byref(hyper), current_stream()))
         self.step_count += 1
 
     def step_forward_loss(self, batch, hyper, out_y=None):

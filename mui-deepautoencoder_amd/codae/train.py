@@ -155,7 +155,9 @@ class HipEmbeddingTrainer:
     """Owns a DaeEngine, the resident dataset and the mask tables; runs train / eval steps."""
 
     def __init__(self, schedule, data, mask_table_u8, mask_to_use_i32, lr, weight_decay, clip=1.0,
-                 max_batch=8192, precision="bf16", device="cuda:0", distributed=False, n_buckets=4):
+                 max_batch=8192, precision="bf16", device="cuda:0", distributed=False, n_buckets=4, use_graph=False):
+        """use_graph: replay the fused step from a hipGraph (codae_train_step_graph): for launch-bound shapes
+        (small batches); single process only - the bucketed data-parallel step is not captured."""
         from .hip.engine import DaeEngine
         self.device = torch.device(device)
         self.engine = DaeEngine(schedule, max_batch, precision, self.device)
@@ -165,6 +167,13 @@ class HipEmbeddingTrainer:
         self.lr, self.weight_decay, self.clip = lr, weight_decay, clip
         self.dp = DataParallel(self.engine, n_buckets=n_buckets) if distributed else None
         self.world = self.dp.world if self.dp else 1
+        self.use_graph = bool(use_graph) and self.dp is None
+        # graph replay freezes kernel arguments: the step's row indices / mask ids are copied into these
+        self._idx_buf = torch.zeros(max_batch, dtype=torch.int32, device=self.device) if self.use_graph else None
+        self._mid_buf = torch.zeros(max_batch, dtype=torch.int32, device=self.device) if self.use_graph else None
+        # (the default stream cannot be captured: graph steps run on a stream of their own, ordered after / before
+        # the caller's current stream)
+        self._graph_stream = torch.cuda.Stream(device=self.device) if self.use_graph else None
 
     # ---- parameters ---------------------------------------------------------------------
     def load_params(self, params):
@@ -197,6 +206,24 @@ class HipEmbeddingTrainer:
         """One optimizer step on rows `row_idx` (int32 device tensor) of the resident dataset.
         global_rows: rows of the whole minibatch over all ranks (default: B * world)."""
         eng = self.engine
+        if self.use_graph:
+            caller = torch.cuda.current_stream(self.device)
+            self._graph_stream.wait_stream(caller)
+            with torch.cuda.stream(self._graph_stream):
+                n = int(row_idx.numel())
+                self._idx_buf[:n].copy_(row_idx)
+                if mask_id is not None:
+                    self._mid_buf[:n].copy_(mask_id)
+                    batch = eng.make_batch(self.data, self._idx_buf[:n], self._mid_buf[:n], self.mask_table)
+                else:
+                    batch = self._batch(self._idx_buf[:n], run)
+                B = batch.B
+                hyper = eng.hyper(self.lr, self.weight_decay, self.clip,
+                                  global_rows=B * self.world if global_rows is None else global_rows)
+                eng.train_step(batch, hyper, graph=True)
+            caller.wait_stream(self._graph_stream)
+            self._keep = batch
+            return B
         if mask_id is None:
             batch = self._batch(row_idx, run)
         else:

@@ -137,8 +137,11 @@ int launch_mse_dense(const float* x, const float* y, const float* fmask, float* 
                      double* scalars, hipStream_t s);
 int launch_sumsq(const float* g, int64_t n, double* out, hipStream_t s);
 // coef_in != null: use that precomputed clip coefficient instead of folding grad_sq + slots
+// step_dev != null: take the step count (bias corrections) from that device scalar instead of hp->step
 int launch_clip_adam(float* p, float* g, float* m, float* v, int64_t n, const codae_hyper* hp,
-                     const double* grad_sq, bf16_t* shadow, const double* coef_in, hipStream_t s);
+                     const double* grad_sq, bf16_t* shadow, const double* coef_in, hipStream_t s,
+                     const double* step_dev = nullptr);
+int launch_set_scalar(double* dst, double value, hipStream_t s);
 // dst[c][r] = src[r][c] for n bf16 matrices (element offsets off[i], shapes rows[i] x cols[i]) in one launch
 int launch_transpose_bf16(const bf16_t* src, bf16_t* dst, int n, const int64_t* off, const int* rows, const int* cols,
                           hipStream_t s);

@@ -276,6 +276,7 @@ __global__ __launch_bounds__(NT) void sumsq_kernel(const float* __restrict__ g, 
 // ---- a7 + a8: clip scale folded into Adam (torch.optim.Adam, amsgrad off, L2 decay) ----------
 struct AdamConst {
     float lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, wd, max_norm;
+    float lr;                // graph replay: the bias corrections are rebuilt on the device from *step_dev
 };
 
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float coef, const AdamConst& c) {
@@ -300,7 +301,14 @@ __global__ void clip_coef_kernel(const double* __restrict__ grad_sq, float max_n
 __global__ __launch_bounds__(NT) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                        float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                        AdamConst c, const double* __restrict__ grad_sq,
-                                                       bf16_t* __restrict__ shadow, const double* __restrict__ coef_in) {
+                                                       bf16_t* __restrict__ shadow, const double* __restrict__ coef_in,
+                                                       const double* __restrict__ step_dev) {
+    if (step_dev != nullptr) {
+        // replayed from a hipGraph: the step count lives in device memory (kernel arguments are frozen at capture)
+        const double t = *step_dev;
+        c.lr_over_bc1 = (float)((double)c.lr / (1.0 - pow((double)c.beta1, t)));
+        c.inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)c.beta2, t)));
+    }
     float coef = 1.f;
     if (coef_in != nullptr) {
         coef = (float)(*coef_in);
@@ -535,8 +543,18 @@ int launch_clip_coef(const double* grad_sq, float max_norm, double* coef_out, hi
     return CODAE_OK;
 }
 
+__global__ void set_scalar_kernel(double* dst, double value) { *dst = value; }
+
+int launch_set_scalar(double* dst, double value, hipStream_t s) {
+    CODAE_REQUIRE(dst != nullptr, "set_scalar: null destination");
+    hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, s, dst, value);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
 int launch_clip_adam(float* p, float* g, float* m, float* v, int64_t n, const codae_hyper* hp,
-                     const double* grad_sq, bf16_t* shadow, const double* coef_in, hipStream_t s) {
+                     const double* grad_sq, bf16_t* shadow, const double* coef_in, hipStream_t s,
+                     const double* step_dev) {
     CODAE_REQUIRE(p && g && m && v && hp && n > 0, "clip_adam: bad args");
     CODAE_REQUIRE(a16(p) && a16(g) && a16(m) && a16(v), "clip_adam: buffers must be 16-byte aligned");
     CODAE_REQUIRE(hp->step >= 1, "clip_adam: step must be >= 1");
@@ -547,8 +565,9 @@ int launch_clip_adam(float* p, float* g, float* m, float* v, int64_t n, const co
     c.lr_over_bc1 = (float)((double)hp->lr / bc1);
     c.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     c.beta1 = hp->beta1; c.beta2 = hp->beta2; c.eps = hp->eps; c.wd = hp->weight_decay;
-    c.max_norm = hp->max_grad_norm;
-    hipLaunchKernelGGL(clip_adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, s, p, g, m, v, n, c, grad_sq, shadow, coef_in);
+    c.max_norm = hp->max_grad_norm; c.lr = hp->lr;
+    hipLaunchKernelGGL(clip_adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, s, p, g, m, v, n, c, grad_sq, shadow, coef_in,
+                       step_dev);
     CODAE_LAUNCH_CHECK();
     return CODAE_OK;
 }

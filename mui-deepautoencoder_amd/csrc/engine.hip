@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "codae_common.h"
+#include <cstring>
 
 namespace codae {
 
@@ -65,6 +66,11 @@ struct codae_engine {
     mutable uint32_t prof_mask = 0;
     mutable int prof_n = 0;
     mutable int prof_every = 1, prof_step = 0;   // launches are timed in every prof_every-th training step only
+    // codae_train_step_graph: the captured step and what it was captured for
+    mutable hipGraphExec_t graph_exec = nullptr;
+    mutable bool capturing = false;          // inside stream capture: device-side Adam step, everything joined at the end
+    mutable bool side2_dirty = false;
+    struct GraphKey { codae_batch batch; codae_hyper hyper; codae_buffers bufs; } mutable graph_key{};
     mutable std::vector<hipEvent_t> prof_start, prof_stop;
     mutable std::vector<int> prof_kind;
     mutable std::vector<int> prof_count;    // launches covered by the record (a GroupScope spans several)
@@ -376,8 +382,11 @@ int join_side(const codae_engine* h, hipStream_t s) {
     if (!h->side_dirty || h->side == nullptr) return CODAE_OK;
     CODAE_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
     CODAE_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join, 0));
-    CODAE_HIP_CHECK(hipEventRecord(h->ev_join2, h->side2));
-    CODAE_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join2, 0));
+    if (h->side2_dirty) {
+        CODAE_HIP_CHECK(hipEventRecord(h->ev_join2, h->side2));
+        CODAE_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join2, 0));
+        h->side2_dirty = false;
+    }
     for (int i = 0; i < CODAE_MAX_DACT; ++i) h->w_pending[i] = false;
     h->side_dirty = false;
     return CODAE_OK;
@@ -441,6 +450,7 @@ int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi
             if (reduce_on_main)
                 rc = run_wgrad(h, b, l, rows, h->side, s, l & 1, slot_busy, true, &was_deferred);
             else
+                if (reduce_stream || (rmode && rmode[0] == 't')) h->side2_dirty = true;
                 rc = run_wgrad(h, b, l, rows, h->side, (reduce_stream || (rmode && rmode[0] == 't')) ? h->side2 : nullptr,
                                l & 1, slot_busy);
             if (rc) return rc;
@@ -566,6 +576,7 @@ static void profile_release(codae_handle h) {
 
 int codae_destroy(codae_handle h) {
     if (h) profile_release(h);
+    if (h && h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
     if (h && h->side) {
         (void)hipStreamSynchronize(h->side);
         (void)hipEventDestroy(h->ev_ready); (void)hipEventDestroy(h->ev_join);
@@ -837,13 +848,14 @@ static int update_impl(codae_handle h, const codae_buffers* b, const codae_hyper
     CODAE_REQUIRE(h->prec != CODAE_PREC_BF16 || shadow, "codae_step_update: shadow_w missing");
     // Measured at C3: hiding Adam under the next forward slows those GEMMs from 46.8 to 56.9 us each (HBM / L2
     // contention) and the step from 1.76 to 1.84 ms, so this is opt-in (CODAE_DEFER_ADAM=1) only.
-    const bool deferred = h->L >= 2 && h->L <= 64 && getenv("CODAE_SINGLE_STREAM") == nullptr && getenv("CODAE_DEFER_ADAM") != nullptr;
+    const bool deferred = !h->capturing && h->L >= 2 && h->L <= 64 && getenv("CODAE_SINGLE_STREAM") == nullptr &&
+                          getenv("CODAE_DEFER_ADAM") != nullptr;
     if (!deferred) {
         int rca;
         {
             ProfScope prof(h, CODAE_K_ADAM, s);
             rca = launch_clip_adam(b->params, b->grads, b->adam_m, b->adam_v, h->n_param, hyper, b->scalars + CODAE_S_GRAD_SQ,
-                                   shadow, nullptr, s);
+                                   shadow, nullptr, s, h->capturing ? b->scalars + CODAE_S_ADAM_STEP : nullptr);
         }
         if (rca) return rca;
         if (h->prec != CODAE_PREC_BF16 || b->shadow_wt == nullptr || h->L < 2) return CODAE_OK;
@@ -858,6 +870,7 @@ static int update_impl(codae_handle h, const codae_buffers* b, const codae_hyper
         if (rcs) return rcs;
         CODAE_HIP_CHECK(hipEventRecord(h->ev_wt, h->side));
         h->wt_pending = true;
+        if (h->capturing) return wait_transposed(h, s);     // a captured graph must end with every branch joined
         return CODAE_OK;
     }
     // Adam is a pure HBM pass (7 x 94 MB at C3) and the forward GEMMs that follow leave HBM mostly idle: update
@@ -929,6 +942,55 @@ int codae_train_step(codae_handle h, const codae_buffers* b, const codae_batch* 
     h->norm_in_backward = false;
     if (rc) return rc;
     return update_impl(h, b, hyper, (hipStream_t)stream, all_slabbed);
+}
+
+static bool same_bytes(const void* a, const void* b, size_t n) { return memcmp(a, b, n) == 0; }
+
+int codae_train_step_graph(codae_handle h, const codae_buffers* b, const codae_batch* batch, const codae_hyper* hyper, void* stream) {
+    CODAE_REQUIRE(h && b && batch && hyper, "codae_train_step_graph: null argument");
+    CODAE_REQUIRE(!h->prof_on, "codae_train_step_graph: launch profiling (codae_profile_begin) cannot run inside a graph");
+    CODAE_REQUIRE(b->scalars != nullptr, "codae_train_step_graph: scalars missing");
+    CODAE_REQUIRE(stream != nullptr, "codae_train_step_graph: the default (null) stream cannot be captured - pass a created stream");
+    hipStream_t s = (hipStream_t)stream;
+    // what the captured kernel arguments depend on (the step count is the one thing that may change)
+    codae_hyper hk = *hyper;
+    hk.step = 0;
+    const bool fresh = h->graph_exec == nullptr || !same_bytes(&h->graph_key.batch, batch, sizeof(*batch)) ||
+                       !same_bytes(&h->graph_key.hyper, &hk, sizeof(hk)) || !same_bytes(&h->graph_key.bufs, b, sizeof(*b));
+    if (fresh) {
+        if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+        int rc = check_common(h, b, batch->B);
+        if (rc) return rc;
+        if (getenv("CODAE_SINGLE_STREAM") == nullptr) {
+            rc = ensure_side_stream(h);                      // (no stream / event creation inside the capture)
+            if (rc) return rc;
+        }
+        rc = codae_join(h, stream);                          // nothing recorded outside may be waited for inside
+        if (rc) return rc;
+        CODAE_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+        h->capturing = true;
+        rc = codae_train_step(h, b, batch, hyper, stream);
+        h->capturing = false;
+        hipGraph_t graph = nullptr;
+        const hipError_t ee = hipStreamEndCapture(s, &graph);
+        if (rc != CODAE_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (ee != hipSuccess || graph == nullptr) {
+            set_error("codae_train_step_graph: stream capture failed: %s", hipGetErrorString(ee));
+            return CODAE_E_HIP;
+        }
+        const hipError_t ei = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ei != hipSuccess) {
+            h->graph_exec = nullptr;
+            set_error("codae_train_step_graph: hipGraphInstantiate failed: %s", hipGetErrorString(ei));
+            return CODAE_E_HIP;
+        }
+        h->graph_key.batch = *batch; h->graph_key.hyper = hk; h->graph_key.bufs = *b;
+    }
+    int rc = launch_set_scalar(b->scalars + CODAE_S_ADAM_STEP, (double)hyper->step, s);
+    if (rc) return rc;
+    CODAE_HIP_CHECK(hipGraphLaunch(h->graph_exec, s));
+    return CODAE_OK;
 }
 
 // ---- stand-alone ops --------------------------------------------------------------------

@@ -428,3 +428,33 @@ def test_two_stream_step_matches_single_stream_over_many_steps(monkeypatch):
         assert abs(x - y) <= 1e-3 * abs(x), (la, lb)
     d = (pa - pb).abs()
     assert float(d.max()) <= 2 * 1e-3 * steps and float(d.mean()) <= 1e-3, (float(d.max()), float(d.mean()))
+
+
+@pytest.mark.parametrize("S,E,B", [(3, 64, 128), (3, 256, 4096)], ids=["small", "bigtile"])
+def test_graph_replay_matches_eager_step(S, E, B):
+    """codae_train_step_graph (whole step, both backward streams, captured once and replayed with the step count in
+    device memory) vs codae_train_step: same parameters after 6 steps up to float-atomics order; fresh row indices go
+    through the persistent index buffer, and Adam's bias correction must follow the step count."""
+    from codae.train import HipEmbeddingTrainer
+    from oracle import dae_oracle as O
+    io = S * E
+    rng = np.random.default_rng(5)
+    N = 3 * B
+    data = rng.random((N, io), dtype=np.float32)
+    sched = O.layer_schedule(io, io, 2, 2, False, "embedding")
+    params = O.init_params(sched, rng)
+    bm, _, _ = O.corrupter_tables([{"size": E, "position": s * E} for s in range(S)], 1)
+    mtu = rng.integers(0, S, (N, 1)).astype(np.int32)
+    order = [torch.tensor(rng.permutation(N)[:B], dtype=torch.int32, device=DEV) for _ in range(6)]
+    out = []
+    for graph in (False, True):
+        tr = HipEmbeddingTrainer(sched, torch.tensor(data), torch.tensor(bm).to(torch.uint8), torch.tensor(mtu), 1e-3, 1e-4, 1.0,
+                                 max_batch=B, precision="bf16", device=DEV, use_graph=graph)
+        tr.load_params(params)
+        for s in range(6):
+            tr.train_batch(order[s], run=0)
+        out.append((tr.engine.params.clone(), tr.engine.read_scalars()))
+    (pa, sa), (pb, sb) = out
+    assert abs(sa[3] - sb[3]) <= 1e-5 * abs(sa[3]), (sa, sb)          # last loss
+    d = (pa - pb).abs()
+    assert float(d.mean()) <= 1e-5 and float(d.max()) <= 2 * 1e-3 * 6, (float(d.mean()), float(d.max()))
