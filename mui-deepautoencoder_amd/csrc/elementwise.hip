@@ -41,6 +41,40 @@ __device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d)
     return o;
 }
 
+// The training step's form of the kernel below (bf16 out, io % 8 == 0): 8 elements per thread = two 16-B loads, one
+// 8-B mask load, one 16-B store (the 4-element form stores 8 B per lane, half-width store instructions).
+__global__ __launch_bounds__(NT) void gather_corrupt_bf16x8_kernel(const float* __restrict__ data,
+                                                                   const int32_t* __restrict__ row_idx,
+                                                                   const int32_t* __restrict__ mask_id,
+                                                                   const uint8_t* __restrict__ table, int B, int io,
+                                                                   bf16_t* __restrict__ out,
+                                                                   const int32_t* __restrict__ mask_to_use, int nb_run,
+                                                                   int run, float* __restrict__ zero_ptr, int64_t zero_n) {
+    const bool masked = (mask_id != nullptr) || (mask_to_use != nullptr);
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < zero_n; e += (int64_t)gridDim.x * NT) zero_ptr[e] = 0.f;
+    const int cols = io / 8;
+    const int64_t total = (int64_t)B * cols;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < total; e += (int64_t)gridDim.x * NT) {
+        const int b = (int)(e / cols);
+        const int c = (int)(e - (int64_t)b * cols) * 8;
+        const int64_t src_row = row_idx ? row_idx[b] : b;
+        const float* src = data + src_row * io + c;
+        const float4 x0 = *reinterpret_cast<const float4*>(src);
+        const float4 x1 = *reinterpret_cast<const float4*>(src + 4);
+        float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        if (masked) {
+            const int id = mask_id ? mask_id[b] : mask_to_use[src_row * nb_run + run];
+            const uint2 m = *reinterpret_cast<const uint2*>(table + (int64_t)id * io + c);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (((k < 4 ? m.x : m.y) >> (8 * (k & 3))) & 0xff) ? v[k] : 0.f;
+        }
+        uint4 o;
+        o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+        o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+        *reinterpret_cast<uint4*>(out + (int64_t)b * io + c) = o;
+    }
+}
+
 // ---- a2 + a10: out[b][:] = data[row_idx[b]][:] * mask_table[mask_id[b]][:] -----------------
 // (collate_embedding data_tool.py:96-103 + corrupt embedding_...py:226-239 fused; the [B,io]
 // fp32 mask of Corrupter.get_masks is never materialised.)
@@ -451,6 +485,13 @@ int launch_gather_corrupt(const codae_batch* b, void* out, int out_bf16, hipStre
     const bool vec = (b->io % 4 == 0) && a16(b->data) && a16(out) && (!masked || (reinterpret_cast<uintptr_t>(b->mask_table) & 3) == 0);
     const int64_t items = (int64_t)b->B * (vec ? b->io / 4 : b->io);
     const int grid = grid_for(items);
+    if (vec && out_bf16 && b->io % 8 == 0 && (!masked || (reinterpret_cast<uintptr_t>(b->mask_table) & 7) == 0)) {
+        hipLaunchKernelGGL(gather_corrupt_bf16x8_kernel, dim3(grid_for(items / 2)), dim3(NT), 0, s, b->data, b->row_idx, b->mask_id,
+                           b->mask_table, b->B, b->io, reinterpret_cast<bf16_t*>(out), b->mask_to_use, b->nb_run, b->run,
+                           zero_ptr, zero_ptr ? zero_n : 0);
+        CODAE_LAUNCH_CHECK();
+        return CODAE_OK;
+    }
 #define GC(V, O) hipLaunchKernelGGL((gather_corrupt_kernel<V, O>), dim3(grid), dim3(NT), 0, s, b->data, b->row_idx, \
                                     b->mask_id, b->mask_table, b->B, b->io, out, b->mask_to_use, b->nb_run, b->run, \
                                     zero_ptr, zero_ptr ? zero_n : 0)
