@@ -406,9 +406,11 @@ int wait_transposed(const codae_engine* h, hipStream_t s) {
 //
 // Two streams: wgrad_l (+ its slab reduce) goes to the side stream as soon as dA_l exists, the
 // dgrad chain stays on `s`; at K = 1536 a third of every GEMM launch is ramp + output drain with
-// all CUs in the same phase, and the two kernels fill each other's bubbles.  dA lives in three
-// rotating buffers: dgrad_l writes buffer (l-1)%3, which wgrad_{l+2} was reading, so it waits for
-// that wgrad's event only.  The call returns with `s` waiting for every side-stream kernel.
+// all CUs in the same phase, and the two kernels fill each other's bubbles.  dA lives in one buffer per
+// layer (n_dact = L + 1, up to CODAE_MAX_DACT): nothing is overwritten within a step, so the dgrad chain never
+// waits for the side stream; deeper stacks rotate (dgrad_l writes buffer (l-1) % n, which wgrad_{l-1+n} was
+// reading, and waits for that wgrad's event).  The last weight gradient (layer 0) runs on `s` itself, beside
+// wgrad_1 on the side stream.  With join the call returns with `s` waiting for every side-stream kernel.
 int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi, float* dx, bool step_mode,
                    hipStream_t s, bool join = true) {
     const int rows = h->rows_for(B);

@@ -8,25 +8,25 @@
 //     first issues the ds_reads of the operand half that quadrant q+1 newly needs, into a second
 //     register set, so the LDS latency is covered by this phase's 24-32 MFMAs (one wave per SIMD:
 //     nobody else would cover it);
-//   * HBM/L2 -> LDS DMA (global_load_lds) runs SEVEN PHASES ahead: a half-tile's LDS region is
-//     dead as soon as its fragments are in registers, and is re-filled in the very next phase with
-//     the same half of the tile two K-tiles later.
+//   * HBM/L2 -> LDS DMA (global_load_lds) runs SIX PHASES ahead: a half-tile's LDS region is re-filled, with the
+//     same half of the tile two K-tiles later, in the SECOND phase after the one that read it (seven phases ahead
+//     = re-fill in the very next phase - was measured too: it forces lgkmcnt(0) at every barrier).
 //
-//      phase   MFMA          fragment read (for)     waits for      LDS-DMA issued (region just freed)
-//      P1(t)   A0 x B0       A1(t)    (P2)           A1(t)          B0(t+2)
-//      P2(t)   A1 x B0       B1(t)    (P3)           B1(t)          A1(t+2)
-//      P3(t)   A1 x B1       A0(t+1)  (P4 .. P1)     A0(t+1)        B1(t+2)
-//      P4(t)   A0 x B1       B0(t+1)  (P1, P2)       B0(t+1)        A0(t+3)
+//      phase   MFMA          fragment read (for)     waits for      LDS-DMA issued (region read two phases ago)
+//      P1(t)   A0 x B0       A1(t)    (P2)           A1(t)          A0(t+2)
+//      P2(t)   A1 x B0       B1(t)    (P3)           B1(t)          B0(t+2)
+//      P3(t)   A1 x B1       A0(t+1)  (P4 .. P1)     A0(t+1)        A1(t+2)
+//      P4(t)   A0 x B1       B0(t+1)  (P1, P2)       B0(t+1)        B1(t+2)
 //
 // DMA is issued in the natural order A0 B0 A1 B1 of tile 0, 1, 2, ... and retires in order, so the
-// half a phase needs is complete once at most the 6 half-tiles issued after it are outstanding:
-// one COUNTED s_waitcnt vmcnt(3a + 3b) per phase (a / b = DMA instructions per wave per A / B
-// half-tile), never a drain inside the loop; then one raw s_barrier per phase, which both
-// publishes every wave's share of the awaited half (RAW: wait -> barrier -> ds_read) and proves the
-// region about to be re-filled is no longer read (WAR: ds_read complete, lgkmcnt(0) -> barrier ->
-// DMA issue).  Both orders hold by construction, not by timing (MI355X guide: "Read a staged
-// buffer one phase AFTER the wait that retires it").  The last two K-tiles of a workgroup, where
-// fewer loads follow, use vmcnt(0).
+// half a phase needs is complete once at most the 5 half-tiles issued after it are outstanding:
+// one COUNTED s_waitcnt per phase - vmcnt(2a + 3b) where an A half is read, vmcnt(3a + 2b) where a B half is
+// (a / b = DMA instructions of this wave per A / B half-tile) - never a drain inside the loop; then one raw
+// s_barrier per phase, which both publishes every wave's share of the awaited half (RAW: wait -> barrier ->
+// ds_read) and proves the region about to be re-filled is no longer read (WAR: its readers ran two phases ago and
+// s_waitcnt lgkmcnt(KEEP) in front of the barrier leaves only the LAST phase's reads in flight -> barrier -> DMA
+// issue).  Both orders hold by construction, not by timing (MI355X guide: "Read a staged buffer one phase AFTER
+// the wait that retires it").  Loads past the last K-tile are issued as dummies, so the counts stay exact.
 //
 // Configurations (4 waves = one per SIMD, the whole 512-entry register file per wave):
 //   256 x 192 (2 x 2 waves, 128 x 96 per wave, a = 4, b = 3): 8192 x 1536 outputs = 256 workgroups
