@@ -94,7 +94,7 @@ enum {
     CODAE_S_GRAD_SQ = 2,     /* sum g^2 of the last codae_step_update (pre-clip)             */
     CODAE_S_LAST_LOSS = 3,   /* mean MSE of the last step (train_dae_on_embedding.py:206)    */
     CODAE_S_STEP_SQ = 4,     /* scratch: sum (x-y)^2 of the current step                     */
-    CODAE_S_CLIP_COEF = 5,   /* two slots (5, 6; step parity): clip coefficient of the last update        */
+    CODAE_S_CLIP_COEF = 5,   /* (5, 6) reserved                                                             */
     CODAE_S_GRAD_SQ_SLOTS = 8, /* 64 partial sums of g^2: same-address atomics serialise (~12 ns each), so
                                   reduction kernels scatter over these slots; sum g^2 = GRAD_SQ + sum(slots) */
     CODAE_S_N_SLOTS = 64,

@@ -146,7 +146,6 @@ int launch_set_scalar(double* dst, double value, hipStream_t s);
 int launch_transpose_bf16(const bf16_t* src, bf16_t* dst, int n, const int64_t* off, const int* rows, const int* cols,
                           hipStream_t s);
 int gemm_bf16_timeline(unsigned long long* host_out, int n_wg);   // CODAE_GEMM_DBG=8 stamps
-int launch_clip_coef(const double* grad_sq, float max_norm, double* coef_out, hipStream_t s);
 // sumsq != null: += sum out^2 (slot-scattered) and, with `extra`, += sum extra[0..n_extra)^2
 int launch_reduce_slabs(const float* slabs, int n_slabs, int64_t slab_stride, float* out, int64_t n, double* sumsq,
                         hipStream_t s, const float* extra = nullptr, int n_extra = 0);

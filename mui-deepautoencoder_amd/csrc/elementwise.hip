@@ -321,17 +321,6 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
     p = p - c.lr_over_bc1 * (m / denom);
 }
 
-// coef_out = min(1, max_norm / (sqrt(sum g^2) + 1e-6)), sum g^2 = scalars[GRAD_SQ] + its slots
-__global__ void clip_coef_kernel(const double* __restrict__ grad_sq, float max_norm, double* __restrict__ coef_out) {
-    double v = grad_sq[(CODAE_S_GRAD_SQ_SLOTS - CODAE_S_GRAD_SQ) + threadIdx.x];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if (threadIdx.x == 0) {
-        const float total = sqrtf((float)(v + grad_sq[0]));
-        *coef_out = (double)fminf(1.f, max_norm / (total + 1e-6f));
-    }
-}
-
 __global__ __launch_bounds__(NT) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                        float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                        AdamConst c, const double* __restrict__ grad_sq,
@@ -573,13 +562,6 @@ int launch_finish_loss(double* scalars, double inv_n, hipStream_t s) {
 int launch_sumsq(const float* g, int64_t n, double* out, hipStream_t s) {
     CODAE_REQUIRE(g && out && n > 0 && a16(g), "sumsq: bad args");
     hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, s, g, n, out);
-    CODAE_LAUNCH_CHECK();
-    return CODAE_OK;
-}
-
-int launch_clip_coef(const double* grad_sq, float max_norm, double* coef_out, hipStream_t s) {
-    CODAE_REQUIRE(grad_sq && coef_out, "clip_coef: null argument");
-    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, s, grad_sq, max_norm, coef_out);
     CODAE_LAUNCH_CHECK();
     return CODAE_OK;
 }

@@ -45,13 +45,8 @@ struct codae_engine {
     // optional per-launch hipEvent pairs (codae_profile_begin / _end)
     // backward on two streams: the weight-gradient GEMMs (+ slab reduce) run on `side`, concurrently with
     // the data-gradient chain on the caller's stream (they only share the read-only dA_l)
-    mutable hipStream_t side = nullptr, side2 = nullptr;   // side2: the HBM-bound slab reduces
-    mutable hipEvent_t ev_ready = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_w[CODAE_MAX_DACT] = {};
-    mutable hipEvent_t ev_g[2] = {nullptr, nullptr}, ev_r[2] = {nullptr, nullptr};   // per slab buffer: GEMM done / reduce done
-    // deferred Adam: layer l's parameters are updated on `side` beside the NEXT forward; forward layer l waits ev_adam[l]
-    mutable hipEvent_t ev_adam[64] = {};
-    mutable bool adam_pending[64] = {};
-    mutable hipEvent_t ev_norm = nullptr;
+    mutable hipStream_t side = nullptr;
+    mutable hipEvent_t ev_ready = nullptr, ev_join = nullptr, ev_w[CODAE_MAX_DACT] = {};
     // the transposed weight shadow is refreshed on `side` after the update (only the NEXT backward reads it):
     // ev_wt_src = Adam done on the caller's stream, ev_wt = transposes done on `side`
     mutable hipEvent_t ev_wt_src = nullptr, ev_wt = nullptr;
@@ -69,7 +64,6 @@ struct codae_engine {
     // codae_train_step_graph: the captured step and what it was captured for
     mutable hipGraphExec_t graph_exec = nullptr;
     mutable bool capturing = false;          // inside stream capture: device-side Adam step, everything joined at the end
-    mutable bool side2_dirty = false;
     struct GraphKey { codae_batch batch; codae_hyper hyper; codae_buffers bufs; } mutable graph_key{};
     mutable std::vector<hipEvent_t> prof_start, prof_stop;
     mutable std::vector<int> prof_kind;
@@ -165,30 +159,10 @@ int check_common(codae_handle h, const codae_buffers* b, int B) {
     return CODAE_OK;
 }
 
-// the parameters of layer l may still be under the previous update's per-layer Adam kernel on the side stream
-int wait_layer_params(const codae_engine* e, int l, hipStream_t s) {
-    if (e->adam_pending[l]) {
-        CODAE_HIP_CHECK(hipStreamWaitEvent(s, e->ev_adam[l], 0));
-        e->adam_pending[l] = false;
-    }
-    return CODAE_OK;
-}
-int wait_all_params(const codae_engine* e, hipStream_t s) {
-    for (int l = 0; l < e->L; ++l) {
-        int rc = wait_layer_params(e, l, s);
-        if (rc) return rc;
-    }
-    return CODAE_OK;
-}
-
 // y = act(x W^T + b) for layer l
 int run_linear(const codae_engine* e, const codae_buffers* b, int l, const void* x, void* y, bool y_f32, int rows,
                hipStream_t s) {
     const int N = e->out[l], K = e->in[l];
-    {
-        int rcw = wait_layer_params(e, l, s);
-        if (rcw) return rcw;
-    }
     ProfScope prof(e, CODAE_K_GEMM_FWD, s);
     if (e->prec == CODAE_PREC_BF16) {
         GemmBf16 g{};
@@ -209,10 +183,8 @@ int run_linear(const codae_engine* e, const codae_buffers* b, int l, const void*
     return gemm_f32(g, s);
 }
 
-// dW_l = dA_l^T act[l].  bf16: split-K partial slabs, then a reduce.  With `rs` != null the reduce goes to that
-// stream and the slabs alternate between two buffers (slot), so the next layer's GEMM need not wait for it.
-int run_wgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, hipStream_t s, hipStream_t rs = nullptr,
-              int slot = 0, bool* slot_busy = nullptr, bool defer_reduce = false, bool* deferred = nullptr) {
+// dW_l = dA_l^T act[l] on stream s.  bf16: split-K partial slabs (slab buffer `slot`), then the reduce on the same stream.
+int run_wgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, hipStream_t s, int slot = 0) {
     const int N = e->out[l], K = e->in[l];
     float* dW = b->grads + e->w_off[l];
     if (e->prec == CODAE_PREC_BF16) {
@@ -224,37 +196,18 @@ int run_wgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, hi
         g.ldc = K; g.c_f32 = 1; g.split_k = S;
         if (S > 1) {
             CODAE_REQUIRE(b->slabs != nullptr, "bf16 wgrad needs the slab workspace");
-            char* slab = reinterpret_cast<char*>(b->slabs) + (int64_t)slot * e->slab_bytes;   // (two slab buffers)
+            char* slab = reinterpret_cast<char*>(b->slabs) + (int64_t)slot * e->slab_bytes;
             g.C = slab;
-            if (rs && slot_busy[slot]) {                   // this buffer's previous reduce must be done
-                CODAE_HIP_CHECK(hipStreamWaitEvent(s, e->ev_r[slot], 0));
-                slot_busy[slot] = false;
-            }
             int rc;
             {
                 ProfScope prof(e, CODAE_K_GEMM_WGRAD, s);
                 rc = gemm_bf16(g, s);
             }
             if (rc) return rc;
-            hipStream_t red = rs ? rs : s;
-            if (rs) CODAE_HIP_CHECK(hipEventRecord(e->ev_g[slot], s));
-            if (rs && defer_reduce) {           // the caller issues run_slab_reduce(l, slot) later
-                *deferred = true;
-                return CODAE_OK;
-            }
-            if (rs) CODAE_HIP_CHECK(hipStreamWaitEvent(rs, e->ev_g[slot], 0));
-            {
-                ProfScope prof(e, CODAE_K_SLAB_REDUCE, red);
-                rc = launch_reduce_slabs(reinterpret_cast<const float*>(slab), S, (int64_t)N * K, dW, (int64_t)N * K,
-                                         e->norm_in_backward ? b->scalars + CODAE_S_GRAD_SQ : nullptr, red,
-                                         b->grads + e->b_off[l], N);
-            }
-            if (rc) return rc;
-            if (rs) {
-                CODAE_HIP_CHECK(hipEventRecord(e->ev_r[slot], rs));
-                slot_busy[slot] = true;
-            }
-            return CODAE_OK;
+            ProfScope prof(e, CODAE_K_SLAB_REDUCE, s);
+            return launch_reduce_slabs(reinterpret_cast<const float*>(slab), S, (int64_t)N * K, dW, (int64_t)N * K,
+                                       e->norm_in_backward ? b->scalars + CODAE_S_GRAD_SQ : nullptr, s,
+                                       b->grads + e->b_off[l], N);
         }
         g.C = dW;
         ProfScope prof(e, CODAE_K_GEMM_WGRAD, s);
@@ -267,24 +220,6 @@ int run_wgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, hi
     g.C = dW; g.ldc = K;
     g.M = N; g.N = K; g.K = rows;
     return gemm_f32(g, s);
-}
-
-// the slab reduce of layer l (slabs in buffer `slot`, GEMM completion = ev_g[slot]) on stream rs
-int run_slab_reduce(const codae_engine* e, const codae_buffers* b, int l, int rows, hipStream_t rs, int slot, bool* slot_busy) {
-    const int N = e->out[l], K = e->in[l];
-    const int S = e->split_k[l] <= rows / 64 ? e->split_k[l] : rows / 64;
-    const char* slab = reinterpret_cast<const char*>(b->slabs) + (int64_t)slot * e->slab_bytes;
-    CODAE_HIP_CHECK(hipStreamWaitEvent(rs, e->ev_g[slot], 0));
-    int rc;
-    {
-        ProfScope prof(e, CODAE_K_SLAB_REDUCE, rs);
-        rc = launch_reduce_slabs(reinterpret_cast<const float*>(slab), S, (int64_t)N * K, b->grads + e->w_off[l], (int64_t)N * K,
-                                 e->norm_in_backward ? b->scalars + CODAE_S_GRAD_SQ : nullptr, rs, b->grads + e->b_off[l], N);
-    }
-    if (rc) return rc;
-    CODAE_HIP_CHECK(hipEventRecord(e->ev_r[slot], rs));
-    slot_busy[slot] = true;
-    return CODAE_OK;
 }
 
 // dA_{l-1} = (dA_l W_l) * [act[l] > 0]  (+ column sums -> db_{l-1});  l == 0 with dx: plain dX in fp32
@@ -361,19 +296,11 @@ int ensure_side_stream(const codae_engine* h) {
     CODAE_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
     const int prio = getenv("CODAE_SIDE_PRIORITY") ? atoi(getenv("CODAE_SIDE_PRIORITY")) : prio_least;
     CODAE_HIP_CHECK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio));
-    CODAE_HIP_CHECK(hipStreamCreateWithPriority(&h->side2, hipStreamNonBlocking, prio));
-    CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming));
-    for (int i = 0; i < 2; ++i) {
-        CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_g[i], hipEventDisableTiming));
-        CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_r[i], hipEventDisableTiming));
-    }
     CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
     CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     for (int i = 0; i < CODAE_MAX_DACT; ++i) CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_w[i], hipEventDisableTiming));
-    CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_norm, hipEventDisableTiming));
     CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_wt_src, hipEventDisableTiming));
     CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_wt, hipEventDisableTiming));
-    for (int l = 0; l < h->L; ++l) CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_adam[l], hipEventDisableTiming));
     return CODAE_OK;
 }
 
@@ -382,11 +309,6 @@ int join_side(const codae_engine* h, hipStream_t s) {
     if (!h->side_dirty || h->side == nullptr) return CODAE_OK;
     CODAE_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
     CODAE_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join, 0));
-    if (h->side2_dirty) {
-        CODAE_HIP_CHECK(hipEventRecord(h->ev_join2, h->side2));
-        CODAE_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join2, 0));
-        h->side2_dirty = false;
-    }
     for (int i = 0; i < CODAE_MAX_DACT; ++i) h->w_pending[i] = false;
     h->side_dirty = false;
     return CODAE_OK;
@@ -415,7 +337,6 @@ int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi
                    hipStream_t s, bool join = true) {
     const int rows = h->rows_for(B);
     const bool dual = getenv("CODAE_SINGLE_STREAM") == nullptr;
-    const bool reduce_stream = false;
     {
         int rcw = wait_transposed(h, s);      // the dgrads read shadow_wt
         if (rcw) return rcw;
@@ -424,70 +345,40 @@ int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi
         int rc = ensure_side_stream(h);
         if (rc) return rc;
     }
+    // (Measured and dropped: the slab reduces on the caller's stream one layer late, or on a third stream - no
+    // gain, 1.83 / 1.84 vs 1.82 ms at the time; every GEMM on the caller's stream with only the reduces beside
+    // them - 0.27 ms slower: each cross-queue event costs ~10 us.)
     bool* w_pending = h->w_pending;
-    bool slot_busy[2] = {false, false};
-    // Where the HBM-bound slab reduces go: behind their GEMM on the side stream (default).  Measured alternatives:
-    // CODAE_REDUCE_STREAM=main issues them on `s` one layer late (two alternating slab buffers) - no difference
-    // (1.83 vs 1.82 ms: the two streams share the same CUs, so the sum of work decides, not the stream balance);
-    // =third uses a third stream - slower (1.84 ms).
-    const char* rmode = getenv("CODAE_REDUCE_STREAM");
-    const bool reduce_on_main = rmode != nullptr && rmode[0] == 'm';
-    const bool gemms_on_main = rmode != nullptr && rmode[0] == 'g';
-    int lag_layer = -1;          // layer whose reduce is still to be issued on s
     for (int l = hi - 1; l >= lo; --l) {
         int rc;
-        bool was_deferred = false;
-        if (dual && gemms_on_main) {
-            // every GEMM on `s` (no gaps, no CU sharing); only the HBM-bound slab reduce goes to the side stream
-            rc = run_wgrad(h, b, l, rows, s, h->side, l & 1, slot_busy);
-            if (rc) return rc;
-        } else if (dual && join && step_mode && l == 0 && hi - lo >= 3 && getenv("CODAE_TAIL_ON_SIDE") == nullptr) {
+        if (!dual) {
+            rc = run_wgrad(h, b, l, rows, s);
+        } else if (join && step_mode && l == 0 && hi - lo >= 3 && getenv("CODAE_TAIL_ON_SIDE") == nullptr) {
             // tail: the side stream still owes wgrad_1 when the dgrad chain ends, and the caller's stream has
             // nothing left to do: the last weight gradient runs here (third slab buffer), beside wgrad_1
-            rc = run_wgrad(h, b, l, rows, s, nullptr, 2);
-            if (rc) return rc;
-        } else if (dual) {
+            rc = run_wgrad(h, b, l, rows, s, 2);
+        } else {
             CODAE_HIP_CHECK(hipEventRecord(h->ev_ready, s));                // dA_l (and act[l]) are complete on s
             CODAE_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_ready, 0));
-            if (reduce_on_main)
-                rc = run_wgrad(h, b, l, rows, h->side, s, l & 1, slot_busy, true, &was_deferred);
-            else
-                if (reduce_stream || (rmode && rmode[0] == 't')) h->side2_dirty = true;
-                rc = run_wgrad(h, b, l, rows, h->side, (reduce_stream || (rmode && rmode[0] == 't')) ? h->side2 : nullptr,
-                               l & 1, slot_busy);
-            if (rc) return rc;
-            if (h->n_dact <= h->L) {            // (with a buffer per layer nothing is ever overwritten within a step)
+            rc = run_wgrad(h, b, l, rows, h->side, l & 1);                  // two alternating slab buffers
+            if (rc == CODAE_OK && h->n_dact <= h->L) {   // (with a buffer per layer nothing is overwritten within a step)
                 CODAE_HIP_CHECK(hipEventRecord(h->ev_w[l % h->n_dact], h->side));
                 w_pending[l % h->n_dact] = true;
             }
-        } else {
-            rc = run_wgrad(h, b, l, rows, s);
-            if (rc) return rc;
         }
+        if (rc) return rc;
         const bool chain = step_mode ? (l > 0) : (l > lo);
         const bool to_dx = !chain && !step_mode && dx != nullptr;
         if (chain || to_dx) {
             // the buffer dgrad_l writes, (l-1) % n, was last read by wgrad_{l-1+n}
             const int wb = (l - 1 + h->n_dact) % h->n_dact;
-            if (dual && !gemms_on_main && chain && w_pending[wb]) {
+            if (dual && chain && w_pending[wb]) {
                 CODAE_HIP_CHECK(hipStreamWaitEvent(s, h->ev_w[wb], 0));
                 w_pending[wb] = false;
             }
             rc = chain ? run_dgrad(h, b, l, rows, nullptr, s) : run_dgrad(h, b, l, B, dx, s);
             if (rc) return rc;
         }
-        if (dual && reduce_on_main) {
-            if (lag_layer >= 0) {              // reduce of the previous layer, now that this layer's dgrad is queued
-                rc = run_slab_reduce(h, b, lag_layer, rows, s, lag_layer & 1, slot_busy);
-                if (rc) return rc;
-                lag_layer = -1;
-            }
-            if (was_deferred) lag_layer = l;
-        }
-    }
-    if (dual && reduce_on_main && lag_layer >= 0) {
-        int rc = run_slab_reduce(h, b, lag_layer, rows, s, lag_layer & 1, slot_busy);
-        if (rc) return rc;
     }
     if (dual) {
         h->side_dirty = true;
@@ -583,13 +474,8 @@ int codae_destroy(codae_handle h) {
         (void)hipStreamSynchronize(h->side);
         (void)hipEventDestroy(h->ev_ready); (void)hipEventDestroy(h->ev_join);
         for (int i = 0; i < CODAE_MAX_DACT; ++i) (void)hipEventDestroy(h->ev_w[i]);
-        (void)hipStreamSynchronize(h->side2);
-        (void)hipEventDestroy(h->ev_norm);
         (void)hipEventDestroy(h->ev_wt_src); (void)hipEventDestroy(h->ev_wt);
-        for (int l = 0; l < h->L; ++l) (void)hipEventDestroy(h->ev_adam[l]);
-        (void)hipEventDestroy(h->ev_join2);
-        for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(h->ev_g[i]); (void)hipEventDestroy(h->ev_r[i]); }
-        (void)hipStreamDestroy(h->side); (void)hipStreamDestroy(h->side2);
+        (void)hipStreamDestroy(h->side);
     }
     delete h;
     return CODAE_OK;
@@ -651,10 +537,6 @@ int codae_param_offsets(codae_handle h, int32_t layer, int64_t* w_off, int64_t* 
 
 int codae_sync_shadows(codae_handle h, const codae_buffers* b, void* stream) {
     CODAE_REQUIRE(h && b && b->params, "codae_sync_shadows: null argument");
-    {
-        int rcw = wait_all_params(h, (hipStream_t)stream);
-        if (rcw) return rcw;
-    }
     if (h->prec != CODAE_PREC_BF16) return CODAE_OK;
     CODAE_REQUIRE(b->shadow_w, "codae_sync_shadows: shadow_w missing");
     {
@@ -702,8 +584,6 @@ int codae_backward(codae_handle h, const codae_buffers* b, const float* dy, floa
     CODAE_REQUIRE(dy && b->grads && b->dacts, "codae_backward: null dy / grads / dacts");
     CODAE_REQUIRE(layer_lo >= 0 && layer_lo < layer_hi && layer_hi <= h->L, "codae_backward: layer range [%d, %d)", layer_lo, layer_hi);
     hipStream_t s = (hipStream_t)stream;
-    rc = wait_all_params(h, s);
-    if (rc) return rc;
     const int rows = h->rows_for(B);
     const int top = layer_hi - 1;
     // bias gradients are accumulated with atomics by the producers of dA_l: clear this range
@@ -751,8 +631,6 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
         const bool last = (l == L - 1);
         if (last && fuse_loss) {
             fwd_group.close();
-            rc = wait_layer_params(h, l, s);
-            if (rc) return rc;
             const double n_glob = (double)(hyper->loss_scale_rows > 0.f ? hyper->loss_scale_rows : (float)B) * batch->io;
             GemmBf16 g{};
             g.A = reinterpret_cast<const bf16_t*>(act_ptr(h, b, l)); g.lda = h->in[l]; g.a_mode = OP_KC;
@@ -848,71 +726,28 @@ static int update_impl(codae_handle h, const codae_buffers* b, const codae_hyper
     }
     bf16_t* shadow = h->prec == CODAE_PREC_BF16 ? reinterpret_cast<bf16_t*>(b->shadow_w) : nullptr;
     CODAE_REQUIRE(h->prec != CODAE_PREC_BF16 || shadow, "codae_step_update: shadow_w missing");
-    // Measured at C3: hiding Adam under the next forward slows those GEMMs from 46.8 to 56.9 us each (HBM / L2
-    // contention) and the step from 1.76 to 1.84 ms, so this is opt-in (CODAE_DEFER_ADAM=1) only.
-    const bool deferred = !h->capturing && h->L >= 2 && h->L <= 64 && getenv("CODAE_SINGLE_STREAM") == nullptr &&
-                          getenv("CODAE_DEFER_ADAM") != nullptr;
-    if (!deferred) {
-        int rca;
-        {
-            ProfScope prof(h, CODAE_K_ADAM, s);
-            rca = launch_clip_adam(b->params, b->grads, b->adam_m, b->adam_v, h->n_param, hyper, b->scalars + CODAE_S_GRAD_SQ,
-                                   shadow, nullptr, s, h->capturing ? b->scalars + CODAE_S_ADAM_STEP : nullptr);
-        }
-        if (rca) return rca;
-        if (h->prec != CODAE_PREC_BF16 || b->shadow_wt == nullptr || h->L < 2) return CODAE_OK;
-        if (getenv("CODAE_SINGLE_STREAM") != nullptr || getenv("CODAE_SYNC_WT") != nullptr) return refresh_transposed(h, b, s);
-        // nothing reads the transposed shadow before the next backward: refresh it on the side stream, beside
-        // the next forward (19 us of HBM-bound copying at C3 off the critical path)
-        int rcs = ensure_side_stream(h);
-        if (rcs) return rcs;
-        CODAE_HIP_CHECK(hipEventRecord(h->ev_wt_src, s));
-        CODAE_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_wt_src, 0));
-        rcs = refresh_transposed(h, b, h->side);
-        if (rcs) return rcs;
-        CODAE_HIP_CHECK(hipEventRecord(h->ev_wt, h->side));
-        h->wt_pending = true;
-        if (h->capturing) return wait_transposed(h, s);     // a captured graph must end with every branch joined
-        return CODAE_OK;
-    }
-    // Adam is a pure HBM pass (7 x 94 MB at C3) and the forward GEMMs that follow leave HBM mostly idle: update
-    // the bias block and layer 0 here, the other layers on the side stream in forward order; the next forward's
-    // layer l waits for event l only.  The clip coefficient is frozen first (the next step resets the norm
-    // scalars while late Adam kernels may still start), in a slot alternating with the step parity.
-    int rc = ensure_side_stream(h);
-    if (rc) return rc;
-    rc = wait_all_params(h, s);          // an update on top of a still-running update: order them
-    if (rc) return rc;
-    const double* coef = nullptr;
-    if (hyper->max_grad_norm > 0.f) {
-        double* slot = b->scalars + CODAE_S_CLIP_COEF + (hyper->step & 1);
-        rc = launch_clip_coef(b->scalars + CODAE_S_GRAD_SQ, hyper->max_grad_norm, slot, s);
-        if (rc) return rc;
-        coef = slot;
-    }
-    auto seg = [&](int64_t off, int64_t n, hipStream_t st) {
-        return launch_clip_adam(b->params + off, b->grads + off, b->adam_m + off, b->adam_v + off, n, hyper, nullptr,
-                                shadow ? shadow + off : nullptr, coef, st);
-    };
+    // (Measured and dropped: per-layer Adam kernels on the side stream beside the NEXT forward - HBM / L2 contention
+    // slowed those GEMMs from 46.8 to 56.9 us each and the step from 1.76 to 1.84 ms.)
+    int rca;
     {
         ProfScope prof(h, CODAE_K_ADAM, s);
-        rc = seg(h->bias_begin, h->n_param - h->bias_begin, s);
-        if (rc) return rc;
-        rc = seg(h->w_off[0], h->w_off[1] - h->w_off[0], s);
-        if (rc) return rc;
+        rca = launch_clip_adam(b->params, b->grads, b->adam_m, b->adam_v, h->n_param, hyper, b->scalars + CODAE_S_GRAD_SQ,
+                               shadow, nullptr, s, h->capturing ? b->scalars + CODAE_S_ADAM_STEP : nullptr);
     }
-    CODAE_HIP_CHECK(hipEventRecord(h->ev_norm, s));
-    CODAE_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_norm, 0));
-    for (int l = 1; l < h->L; ++l) {
-        const int64_t end = (l + 1 < h->L) ? h->w_off[l + 1] : h->bias_begin;
-        ProfScope prof(h, CODAE_K_ADAM, h->side);
-        rc = seg(h->w_off[l], end - h->w_off[l], h->side);
-        if (rc) return rc;
-        rc = refresh_transposed(h, b, h->side, l, l + 1);
-        if (rc) return rc;
-        CODAE_HIP_CHECK(hipEventRecord(h->ev_adam[l], h->side));
-        h->adam_pending[l] = true;
-    }
+    if (rca) return rca;
+    if (h->prec != CODAE_PREC_BF16 || b->shadow_wt == nullptr || h->L < 2) return CODAE_OK;
+    if (getenv("CODAE_SINGLE_STREAM") != nullptr || getenv("CODAE_SYNC_WT") != nullptr) return refresh_transposed(h, b, s);
+    // nothing reads the transposed shadow before the next backward: refresh it on the side stream, beside
+    // the next forward (19 us of HBM-bound copying at C3 off the critical path)
+    int rcs = ensure_side_stream(h);
+    if (rcs) return rcs;
+    CODAE_HIP_CHECK(hipEventRecord(h->ev_wt_src, s));
+    CODAE_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_wt_src, 0));
+    rcs = refresh_transposed(h, b, h->side);
+    if (rcs) return rcs;
+    CODAE_HIP_CHECK(hipEventRecord(h->ev_wt, h->side));
+    h->wt_pending = true;
+    if (h->capturing) return wait_transposed(h, s);     // a captured graph must end with every branch joined
     return CODAE_OK;
 }
 
@@ -924,9 +759,7 @@ int codae_join(codae_handle h, void* stream) {
     CODAE_REQUIRE(h != nullptr, "codae_join: null handle");
     int rc = wait_transposed(h, (hipStream_t)stream);
     if (rc) return rc;
-    rc = join_side(h, (hipStream_t)stream);
-    if (rc) return rc;
-    return wait_all_params(h, (hipStream_t)stream);
+    return join_side(h, (hipStream_t)stream);
 }
 
 int codae_train_step(codae_handle h, const codae_buffers* b, const codae_batch* batch, const codae_hyper* hyper, void* stream) {
