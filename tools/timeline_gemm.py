@@ -26,6 +26,8 @@ for K in [int(a) for a in sys.argv[1:]] or [1536]:
     e0.record()
     hip.check(L.codae_linear_bf16(hip.ptr(x), hip.ptr(W), hip.ptr(b), hip.ptr(y), 0, M, N, K, 1, st))
     e1.record(); torch.cuda.synchronize()
+    ref = torch.relu(x.float() @ W.float().T + b)
+    print("  max |y - torch fp32 reference| = %.4f (bf16 output, |y| up to %.1f)" % (float((y.float() - ref).abs().max()), float(ref.abs().max())))
     out = np.zeros((NWG, 6), dtype=np.uint64)
     hip.check(L.codae_debug_gemm_timeline(out.ctypes.data, NWG))
     t = out[:, :5].astype(np.int64)
