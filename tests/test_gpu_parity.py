@@ -458,3 +458,50 @@ def test_graph_replay_matches_eager_step(S, E, B):
     assert abs(sa[3] - sb[3]) <= 1e-5 * abs(sa[3]), (sa, sb)          # last loss
     d = (pa - pb).abs()
     assert float(d.mean()) <= 1e-5 and float(d.max()) <= 2 * 1e-3 * 6, (float(d.mean()), float(d.max()))
+
+
+def _fuzz_cases():
+    rng = np.random.default_rng(2024)
+    cases = []
+    for _ in range(8):
+        S = int(rng.integers(3, 6))            # (k_max = 1 needs at least 3 slots: Corrupter's own check)
+        E = int(rng.choice([64, 128, 192, 320]))
+        io = S * E
+        z = int(rng.choice([io, max(64, (io // 2) // 64 * 64), 64]))
+        B = int(rng.integers(65, 2600))
+        cases.append((S, E, z, int(rng.integers(2, 5)), int(rng.integers(2, 5)), B))   # (1 layer per side: the reference itself raises)
+    return cases
+
+
+@pytest.mark.parametrize("S,E,z,nb_in,nb_out,B", _fuzz_cases())
+def test_fused_random_topologies_vs_oracle(S, E, z, nb_in, nb_out, B):
+    """Seeded random stacks (tapers to z, 2-4 hidden layers per side, ragged batches, every tile / split-K choice
+    the dispatcher makes for them): two fused steps against the fp32 oracle - bf16 kernels when every width is a multiple
+    of 64 (loss within 2 %, grad-norm 10 %), exact-fp32 kernels otherwise (1e-3 / 5e-3)."""
+    from codae.train import HipEmbeddingTrainer
+    from oracle import dae_oracle as O
+    io = S * E
+    rng = np.random.default_rng(S * 1000 + E + B)
+    sched = O.layer_schedule(io, z, nb_in, nb_out, False, "embedding")
+    # widths that are not multiples of 64 exist only in the exact-fp32 mode (any shape): tighter tolerance there
+    precision = "f32" if any(k % 64 or n % 64 for k, n, _ in sched) else "bf16"
+    tol = 1e-3 if precision == "f32" else 2e-2
+    N = 2 * B
+    data = rng.random((N, io), dtype=np.float32)
+    params = O.init_params(sched, rng)
+    arch = [{"size": E, "position": s * E} for s in range(S)]
+    bm, nmr, _ = O.corrupter_tables(arch, 1)
+    mtu = np.stack([rng.permutation(S) for _ in range(N)])
+    lr, wd = 1e-3, 1e-4
+    tr = HipEmbeddingTrainer(sched, torch.tensor(data), torch.tensor(bm).to(torch.uint8), torch.tensor(mtu).to(torch.int32),
+                             lr, wd, 1.0, max_batch=B, precision=precision, device=DEV)
+    tr.load_params(params)
+    orc = O.EmbeddingTrainer(params, [r for _, _, r in sched], lr, wd)
+    for s in range(2):
+        idx = rng.permutation(N)[:B]
+        _, fmask = O.get_masks(bm, nmr, mtu, 1, idx, 0)
+        ro = orc.step(data[idx], fmask)
+        tr.train_batch(torch.tensor(idx, dtype=torch.int32, device=DEV), run=0)
+        sq, sqp, gsq, loss = tr.engine.read_scalars()
+        assert abs(loss - float(ro["loss"])) <= tol * abs(float(ro["loss"])), (precision, s, loss, ro["loss"])
+        assert abs(math.sqrt(gsq) - float(ro["grad_norm"])) <= 5 * tol * float(ro["grad_norm"]), (precision, s, math.sqrt(gsq), ro["grad_norm"])
