@@ -57,6 +57,7 @@ struct codae_engine {
     mutable bool side_dirty = false;      // side-stream work not yet joined into the caller's stream
     // single-GPU fused step: the slab reduce of every layer also accumulates sum g^2 (clip_grad_norm_)
     mutable bool norm_in_backward = false;
+    mutable bool norm_scalars_zero = false;   // finish_loss of this step zeroed GRAD_SQ + its slots and nothing added since
     mutable bool prof_on = false;
     mutable uint32_t prof_mask = 0;
     mutable int prof_n = 0;
@@ -648,6 +649,7 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
                 rc = gemm_bf16(g, s);
             }
             if (rc) return rc;
+            h->norm_scalars_zero = true;
             return launch_finish_loss(b->scalars, 1.0 / ((double)B * batch->io), s);
         }
         rc = last ? run_linear(h, b, l, act_ptr(h, b, l), y, true, B, s)
@@ -666,6 +668,7 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
                                  b->scalars, 1, s);
         }
         if (rc) return rc;
+        h->norm_scalars_zero = true;
         return launch_finish_loss(b->scalars, 1.0 / ((double)B * batch->io), s);
     }
     rc = launch_mse_loss(batch, y, nullptr, 0, 0.f, nullptr, b->scalars, 0, s);
@@ -712,14 +715,19 @@ static int update_impl(codae_handle h, const codae_buffers* b, const codae_hyper
         rcw = join_side(h, s);                // (a backward issued with codae_step_backward_async)
         if (rcw) return rcw;
     }
+    const bool scalars_zero = h->norm_scalars_zero;
+    h->norm_scalars_zero = false;
+    (void)scalars_zero;
     if (hyper->max_grad_norm > 0.f) {
         ProfScope prof(h, CODAE_K_SUMSQ, s);
         int rc;
         if (weights_norm_done) {
             rc = CODAE_OK;     // sum g^2 of every weight and bias gradient was accumulated by the slab reduces
         } else {
-            CODAE_HIP_CHECK(hipMemsetAsync(b->scalars + CODAE_S_GRAD_SQ, 0, sizeof(double), s));
-            CODAE_HIP_CHECK(hipMemsetAsync(b->scalars + CODAE_S_GRAD_SQ_SLOTS, 0, CODAE_S_N_SLOTS * sizeof(double), s));
+            if (!scalars_zero) {                 // (a stand-alone update: no step_forward_loss of this step cleared them)
+                CODAE_HIP_CHECK(hipMemsetAsync(b->scalars + CODAE_S_GRAD_SQ, 0, sizeof(double), s));
+                CODAE_HIP_CHECK(hipMemsetAsync(b->scalars + CODAE_S_GRAD_SQ_SLOTS, 0, CODAE_S_N_SLOTS * sizeof(double), s));
+            }
             rc = launch_sumsq(b->grads, h->n_param, b->scalars + CODAE_S_GRAD_SQ, s);
         }
         if (rc) return rc;
