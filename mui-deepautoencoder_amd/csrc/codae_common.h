@@ -142,6 +142,12 @@ int launch_clip_adam(float* p, float* g, float* m, float* v, int64_t n, const co
                      const double* grad_sq, bf16_t* shadow, const double* coef_in, hipStream_t s,
                      const double* step_dev = nullptr);
 int launch_set_scalar(double* dst, double value, hipStream_t s);
+// bf16 engine: Adam over the weight matrices in tiles, writing the bf16 shadow AND (layers >= transposed_from) the
+// transposed shadow in the same pass; the flat bias block [bias_off, bias_off + bias_n) rides along
+int launch_clip_adam_tiled(float* p, float* g, float* m, float* v, const codae_hyper* hp, const double* grad_sq,
+                           bf16_t* shadow, bf16_t* shadow_t, int n_layers, const int64_t* w_off, const int* rows,
+                           const int* cols, int transposed_from, int64_t bias_off, int64_t bias_n, hipStream_t s,
+                           const double* step_dev = nullptr);
 // dst[c][r] = src[r][c] for n bf16 matrices (element offsets off[i], shapes rows[i] x cols[i]) in one launch
 int launch_transpose_bf16(const bf16_t* src, bf16_t* dst, int n, const int64_t* off, const int* rows, const int* cols,
                           hipStream_t s);

@@ -566,6 +566,102 @@ int launch_sumsq(const float* g, int64_t n, double* out, hipStream_t s) {
     return CODAE_OK;
 }
 
+// Tiled form of clip_adam for the bf16 engine: the weight matrices are walked in 64 x 128 tiles so that the same
+// pass can also write the TRANSPOSED bf16 shadow (Wt_l [in][out], what the data-gradient GEMM reads) through LDS;
+// the blocks past the last tile do the flat bias block.  Replaces clip_adam_kernel + transpose_bf16_kernel: 85 MB
+// less traffic per step at C3 and no cross-stream hand-off for the transposes.
+struct AdamTiles {
+    int n_layers;
+    int64_t off[64];          // element offset of W_l in the flat vectors (same in the shadows)
+    int rows[64], cols[64];   // W_l is [rows = out][cols = in]
+    int tile_begin[65];       // prefix sum of 64 x 128 tiles per layer
+    int transposed_from;      // layers >= this also get the transposed shadow
+    int64_t bias_off, bias_n; // flat tail
+};
+constexpr int AT_R = 64, AT_C = 128;
+
+__global__ __launch_bounds__(NT) void clip_adam_tiled_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                             float* __restrict__ m, float* __restrict__ v, AdamConst c,
+                                                             const double* __restrict__ grad_sq, bf16_t* __restrict__ shadow,
+                                                             bf16_t* __restrict__ shadow_t, AdamTiles jobs,
+                                                             const double* __restrict__ step_dev) {
+    __shared__ bf16_t tt[AT_C][AT_R + 8];          // transposed tile: [col][row], rows stay 16-byte aligned
+    __shared__ double total_sq;
+    if (step_dev != nullptr) {
+        const double t = *step_dev;
+        c.lr_over_bc1 = (float)((double)c.lr / (1.0 - pow((double)c.beta1, t)));
+        c.inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)c.beta2, t)));
+    }
+    float coef = 1.f;
+    if (c.max_norm > 0.f) {
+        if (threadIdx.x < 64) {
+            double sv = grad_sq[(CODAE_S_GRAD_SQ_SLOTS - CODAE_S_GRAD_SQ) + threadIdx.x];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sv += __shfl_xor(sv, o);
+            if (threadIdx.x == 0) total_sq = sv + grad_sq[0];
+        }
+        __syncthreads();
+        coef = fminf(1.f, c.max_norm / (sqrtf((float)total_sq) + 1e-6f));
+    }
+    const int n_tiles = jobs.tile_begin[jobs.n_layers];
+    if ((int)blockIdx.x >= n_tiles) {
+        // flat bias block, grid-strided over the remaining blocks
+        const int64_t nb = (int64_t)gridDim.x - n_tiles;
+        for (int64_t e = ((int64_t)blockIdx.x - n_tiles) * NT + threadIdx.x; e < jobs.bias_n; e += nb * NT) {
+            const int64_t i = jobs.bias_off + e;
+            float pp = p[i], mm = m[i], vv = v[i];
+            adam_one(pp, g[i], mm, vv, coef, c);
+            p[i] = pp; m[i] = mm; v[i] = vv;
+            shadow[i] = f32_to_bf16(pp);
+        }
+        return;
+    }
+    int l = 0;
+    while (l + 1 < jobs.n_layers && (int)blockIdx.x >= jobs.tile_begin[l + 1]) ++l;
+    const int t = blockIdx.x - jobs.tile_begin[l];
+    const int R = jobs.rows[l], C = jobs.cols[l];
+    const int tiles_c = (C + AT_C - 1) / AT_C;
+    const int r0 = (t / tiles_c) * AT_R, c0 = (t % tiles_c) * AT_C;
+    const int64_t base = jobs.off[l];
+    const bool want_t = shadow_t != nullptr && l >= jobs.transposed_from;
+#pragma unroll
+    for (int it = 0; it < AT_R * AT_C / 4 / NT; ++it) {
+        const int q = threadIdx.x + it * NT;          // float4 index inside the tile
+        const int r = q / (AT_C / 4), cc = (q % (AT_C / 4)) * 4;
+        if (r0 + r < R && c0 + cc < C) {
+            const int64_t e = base + (int64_t)(r0 + r) * C + c0 + cc;
+            float4 pp = *reinterpret_cast<float4*>(p + e);
+            const float4 gg = *reinterpret_cast<const float4*>(g + e);
+            float4 mm = *reinterpret_cast<float4*>(m + e);
+            float4 vv = *reinterpret_cast<float4*>(v + e);
+            adam_one(pp.x, gg.x, mm.x, vv.x, coef, c);
+            adam_one(pp.y, gg.y, mm.y, vv.y, coef, c);
+            adam_one(pp.z, gg.z, mm.z, vv.z, coef, c);
+            adam_one(pp.w, gg.w, mm.w, vv.w, coef, c);
+            *reinterpret_cast<float4*>(p + e) = pp;
+            *reinterpret_cast<float4*>(m + e) = mm;
+            *reinterpret_cast<float4*>(v + e) = vv;
+            const uint2 sh = pack_bf16x4(pp.x, pp.y, pp.z, pp.w);
+            *reinterpret_cast<uint2*>(shadow + e) = sh;
+            if (want_t) {
+                tt[cc + 0][r] = (bf16_t)(sh.x & 0xffff); tt[cc + 1][r] = (bf16_t)(sh.x >> 16);
+                tt[cc + 2][r] = (bf16_t)(sh.y & 0xffff); tt[cc + 3][r] = (bf16_t)(sh.y >> 16);
+            }
+        }
+    }
+    if (!want_t) return;
+    __syncthreads();
+    // Wt[c0 + c][r0 .. r0 + 63]: 128-B row segments, 16 B per lane
+#pragma unroll
+    for (int it = 0; it < AT_C * (AT_R / 8) / NT; ++it) {
+        const int q = threadIdx.x + it * NT;
+        const int cidx = q / (AT_R / 8), r8 = (q % (AT_R / 8)) * 8;
+        if (c0 + cidx < C && r0 + r8 < R)
+            *reinterpret_cast<uint4*>(shadow_t + base + (int64_t)(c0 + cidx) * R + r0 + r8) =
+                *reinterpret_cast<const uint4*>(&tt[cidx][r8]);
+    }
+}
+
 __global__ void set_scalar_kernel(double* dst, double value) { *dst = value; }
 
 int launch_set_scalar(double* dst, double value, hipStream_t s) {
@@ -591,6 +687,38 @@ int launch_clip_adam(float* p, float* g, float* m, float* v, int64_t n, const co
     c.max_norm = hp->max_grad_norm; c.lr = hp->lr;
     hipLaunchKernelGGL(clip_adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, s, p, g, m, v, n, c, grad_sq, shadow, coef_in,
                        step_dev);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+int launch_clip_adam_tiled(float* p, float* g, float* m, float* v, const codae_hyper* hp, const double* grad_sq,
+                           bf16_t* shadow, bf16_t* shadow_t, int n_layers, const int64_t* w_off, const int* rows,
+                           const int* cols, int transposed_from, int64_t bias_off, int64_t bias_n, hipStream_t s,
+                           const double* step_dev) {
+    CODAE_REQUIRE(p && g && m && v && hp && shadow && n_layers > 0 && n_layers <= 64, "clip_adam_tiled: bad args");
+    CODAE_REQUIRE(a16(p) && a16(g) && a16(m) && a16(v), "clip_adam_tiled: buffers must be 16-byte aligned");
+    CODAE_REQUIRE(hp->step >= 1, "clip_adam_tiled: step must be >= 1");
+    CODAE_REQUIRE(hp->max_grad_norm <= 0.f || grad_sq, "clip_adam_tiled: clipping needs the grad_sq scalar");
+    AdamConst c;
+    const double bc1 = 1.0 - pow((double)hp->beta1, (double)hp->step);
+    const double bc2 = 1.0 - pow((double)hp->beta2, (double)hp->step);
+    c.lr_over_bc1 = (float)((double)hp->lr / bc1);
+    c.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    c.beta1 = hp->beta1; c.beta2 = hp->beta2; c.eps = hp->eps; c.wd = hp->weight_decay;
+    c.max_norm = hp->max_grad_norm; c.lr = hp->lr;
+    AdamTiles jobs;
+    jobs.n_layers = n_layers; jobs.transposed_from = transposed_from; jobs.bias_off = bias_off; jobs.bias_n = bias_n;
+    int total = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        CODAE_REQUIRE(rows[l] % 8 == 0 && cols[l] % 4 == 0 && w_off[l] % 8 == 0, "clip_adam_tiled: layer %d shape %d x %d", l, rows[l], cols[l]);
+        jobs.off[l] = w_off[l]; jobs.rows[l] = rows[l]; jobs.cols[l] = cols[l];
+        jobs.tile_begin[l] = total;
+        total += ((rows[l] + AT_R - 1) / AT_R) * ((cols[l] + AT_C - 1) / AT_C);
+    }
+    jobs.tile_begin[n_layers] = total;
+    const int bias_blocks = (int)((bias_n + NT * 8 - 1) / (NT * 8)) > 0 ? (int)((bias_n + NT * 8 - 1) / (NT * 8)) : 1;
+    hipLaunchKernelGGL(clip_adam_tiled_kernel, dim3(total + bias_blocks), dim3(NT), 0, s, p, g, m, v, c, grad_sq, shadow, shadow_t,
+                       jobs, step_dev);
     CODAE_LAUNCH_CHECK();
     return CODAE_OK;
 }

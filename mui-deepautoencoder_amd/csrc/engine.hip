@@ -47,10 +47,6 @@ struct codae_engine {
     // the data-gradient chain on the caller's stream (they only share the read-only dA_l)
     mutable hipStream_t side = nullptr;
     mutable hipEvent_t ev_ready = nullptr, ev_join = nullptr, ev_w[CODAE_MAX_DACT] = {};
-    // the transposed weight shadow is refreshed on `side` after the update (only the NEXT backward reads it):
-    // ev_wt_src = Adam done on the caller's stream, ev_wt = transposes done on `side`
-    mutable hipEvent_t ev_wt_src = nullptr, ev_wt = nullptr;
-    mutable bool wt_pending = false;
     // dA buffer i is still being read by a side-stream wgrad (event ev_w[i]); kept across calls so that a backward
     // issued bucket by bucket without joins (codae_step_backward_async) stays ordered
     mutable bool w_pending[CODAE_MAX_DACT] = {};
@@ -300,8 +296,6 @@ int ensure_side_stream(const codae_engine* h) {
     CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
     CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     for (int i = 0; i < CODAE_MAX_DACT; ++i) CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_w[i], hipEventDisableTiming));
-    CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_wt_src, hipEventDisableTiming));
-    CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_wt, hipEventDisableTiming));
     return CODAE_OK;
 }
 
@@ -312,14 +306,6 @@ int join_side(const codae_engine* h, hipStream_t s) {
     CODAE_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join, 0));
     for (int i = 0; i < CODAE_MAX_DACT; ++i) h->w_pending[i] = false;
     h->side_dirty = false;
-    return CODAE_OK;
-}
-
-// stream s may touch shadow_w / shadow_wt once the side-stream transposes of the last update are done
-int wait_transposed(const codae_engine* h, hipStream_t s) {
-    if (!h->wt_pending) return CODAE_OK;
-    CODAE_HIP_CHECK(hipStreamWaitEvent(s, h->ev_wt, 0));
-    h->wt_pending = false;
     return CODAE_OK;
 }
 
@@ -338,10 +324,6 @@ int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi
                    hipStream_t s, bool join = true) {
     const int rows = h->rows_for(B);
     const bool dual = getenv("CODAE_SINGLE_STREAM") == nullptr;
-    {
-        int rcw = wait_transposed(h, s);      // the dgrads read shadow_wt
-        if (rcw) return rcw;
-    }
     if (dual) {
         int rc = ensure_side_stream(h);
         if (rc) return rc;
@@ -475,7 +457,6 @@ int codae_destroy(codae_handle h) {
         (void)hipStreamSynchronize(h->side);
         (void)hipEventDestroy(h->ev_ready); (void)hipEventDestroy(h->ev_join);
         for (int i = 0; i < CODAE_MAX_DACT; ++i) (void)hipEventDestroy(h->ev_w[i]);
-        (void)hipEventDestroy(h->ev_wt_src); (void)hipEventDestroy(h->ev_wt);
         (void)hipStreamDestroy(h->side);
     }
     delete h;
@@ -540,10 +521,6 @@ int codae_sync_shadows(codae_handle h, const codae_buffers* b, void* stream) {
     CODAE_REQUIRE(h && b && b->params, "codae_sync_shadows: null argument");
     if (h->prec != CODAE_PREC_BF16) return CODAE_OK;
     CODAE_REQUIRE(b->shadow_w, "codae_sync_shadows: shadow_w missing");
-    {
-        int rcw = wait_transposed(h, (hipStream_t)stream);
-        if (rcw) return rcw;
-    }
     int rc = launch_cast_bf16(b->params, reinterpret_cast<bf16_t*>(b->shadow_w), h->n_param, (hipStream_t)stream);
     if (rc) return rc;
     return refresh_transposed(h, b, (hipStream_t)stream);
@@ -710,9 +687,7 @@ static int update_impl(codae_handle h, const codae_buffers* b, const codae_hyper
     CODAE_REQUIRE(h && b && hyper, "codae_step_update: null argument");
     CODAE_REQUIRE(b->params && b->grads && b->adam_m && b->adam_v && b->scalars, "codae_step_update: buffer missing");
     {
-        int rcw = wait_transposed(h, s);      // Adam rewrites shadow_w, which a pending transpose still reads
-        if (rcw) return rcw;
-        rcw = join_side(h, s);                // (a backward issued with codae_step_backward_async)
+        int rcw = join_side(h, s);            // (a backward issued with codae_step_backward_async)
         if (rcw) return rcw;
     }
     const bool scalars_zero = h->norm_scalars_zero;
@@ -736,27 +711,18 @@ static int update_impl(codae_handle h, const codae_buffers* b, const codae_hyper
     CODAE_REQUIRE(h->prec != CODAE_PREC_BF16 || shadow, "codae_step_update: shadow_w missing");
     // (Measured and dropped: per-layer Adam kernels on the side stream beside the NEXT forward - HBM / L2 contention
     // slowed those GEMMs from 46.8 to 56.9 us each and the step from 1.76 to 1.84 ms.)
-    int rca;
-    {
-        ProfScope prof(h, CODAE_K_ADAM, s);
-        rca = launch_clip_adam(b->params, b->grads, b->adam_m, b->adam_v, h->n_param, hyper, b->scalars + CODAE_S_GRAD_SQ,
-                               shadow, nullptr, s, h->capturing ? b->scalars + CODAE_S_ADAM_STEP : nullptr);
+    const double* step_dev = h->capturing ? b->scalars + CODAE_S_ADAM_STEP : nullptr;
+    ProfScope prof(h, CODAE_K_ADAM, s);
+    if (h->prec == CODAE_PREC_BF16 && b->shadow_wt != nullptr && h->L <= 64 && getenv("CODAE_FLAT_ADAM") == nullptr) {
+        // one tiled pass: p, m, v, the bf16 shadow and the transposed shadow of every layer that has a data gradient
+        return launch_clip_adam_tiled(b->params, b->grads, b->adam_m, b->adam_v, hyper, b->scalars + CODAE_S_GRAD_SQ, shadow,
+                                      reinterpret_cast<bf16_t*>(b->shadow_wt), h->L, h->w_off.data(), h->out.data(), h->in.data(),
+                                      1, h->bias_begin, h->n_param - h->bias_begin, s, step_dev);
     }
+    int rca = launch_clip_adam(b->params, b->grads, b->adam_m, b->adam_v, h->n_param, hyper, b->scalars + CODAE_S_GRAD_SQ,
+                               shadow, nullptr, s, step_dev);
     if (rca) return rca;
-    if (h->prec != CODAE_PREC_BF16 || b->shadow_wt == nullptr || h->L < 2) return CODAE_OK;
-    if (getenv("CODAE_SINGLE_STREAM") != nullptr || getenv("CODAE_SYNC_WT") != nullptr) return refresh_transposed(h, b, s);
-    // nothing reads the transposed shadow before the next backward: refresh it on the side stream, beside
-    // the next forward (19 us of HBM-bound copying at C3 off the critical path)
-    int rcs = ensure_side_stream(h);
-    if (rcs) return rcs;
-    CODAE_HIP_CHECK(hipEventRecord(h->ev_wt_src, s));
-    CODAE_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_wt_src, 0));
-    rcs = refresh_transposed(h, b, h->side);
-    if (rcs) return rcs;
-    CODAE_HIP_CHECK(hipEventRecord(h->ev_wt, h->side));
-    h->wt_pending = true;
-    if (h->capturing) return wait_transposed(h, s);     // a captured graph must end with every branch joined
-    return CODAE_OK;
+    return refresh_transposed(h, b, s);
 }
 
 int codae_step_update(codae_handle h, const codae_buffers* b, const codae_hyper* hyper, void* stream) {
@@ -765,8 +731,6 @@ int codae_step_update(codae_handle h, const codae_buffers* b, const codae_hyper*
 
 int codae_join(codae_handle h, void* stream) {
     CODAE_REQUIRE(h != nullptr, "codae_join: null handle");
-    int rc = wait_transposed(h, (hipStream_t)stream);
-    if (rc) return rc;
     return join_side(h, (hipStream_t)stream);
 }
 
