@@ -278,7 +278,8 @@ int codae_wgrad_bf16(const void* dy, const void* x, float* dW, void* slabs, int6
 int codae_debug_gemm_timeline(uint64_t* host_out, int32_t n_wg);
 int codae_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* dst[c][r] = src[r][c] on bf16 matrices (rows, cols multiples of 8): the kernel that refreshes codae_buffers.shadow_wt
- * after each parameter update (W.t() in torch.nn.Linear's data gradient, embedding_denoising_autoencoder.py:137-151). */
+ * after an EXTERNAL parameter update (codae_sync_shadows); codae_step_update writes it inside its Adam pass
+ * (W.t() in torch.nn.Linear's data gradient, embedding_denoising_autoencoder.py:137-151). */
 int codae_transpose_bf16(const void* src, void* dst, int32_t rows, int32_t cols, void* stream);
 
 #ifdef __cplusplus
