@@ -30,7 +30,7 @@ def classify(name):
         return "gemm_dgrad" if epi == "2" else "gemm_fwd"
     if "gemm_bf16_kernel" in name and name.replace(" ", "").endswith("true>(codae::GemmBf16,int,int,int)"):
         return "loss_gemm"
-    for key, cls in (("clip_adam", "adam"), ("reduce_slabs", "slab_reduce"), ("gather_corrupt", "gather"),
+    for key, cls in (("clip_adam_tiled", "adam_tiled"), ("clip_adam", "adam"), ("reduce_slabs", "slab_reduce"), ("gather_corrupt", "gather"),
                      ("transpose_bf16", "transpose"), ("cast_bf16", "cast_bf16")):
         if key in name:
             return cls
