@@ -34,3 +34,25 @@ fl = 2.0 * M * N * K
 for name, v in res.items():
     v = sorted(v[1:]); med = v[len(v) // 2]
     print("%-52s median %7.1f us  %6.0f TFLOP/s" % (name, med, fl / med / 1e6))
+
+# the weight-gradient shape: dW[N][K] = dY[M][N]^T X[M][K] (fp32 accumulate; the library writes bf16 or fp32)
+dy = (torch.randn(M, N, generator=g) * 1e-2).to(dev).bfloat16()
+dW32 = torch.empty(N, K, device=dev)
+slabs = torch.empty(8 * N * K, device=dev)
+ops2 = {
+    "this build: codae_wgrad_bf16 (split-K slabs + reduce, fp32 out)": lambda: hip.check(L.codae_wgrad_bf16(hip.ptr(dy), hip.ptr(x), hip.ptr(dW32), hip.ptr(slabs), slabs.numel() * 4, M, N, K, st)),
+    "torch.matmul(dY.t(), X) (bf16 out)": lambda: torch.matmul(dy.t(), x),
+}
+res2 = {k: [] for k in ops2}
+for rnd in range(6):
+    for name, f in ops2.items():
+        for _ in range(5): f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): f()
+        e1.record(); torch.cuda.synchronize()
+        res2[name].append(e0.elapsed_time(e1) / 20 * 1e3)
+for name, v in res2.items():
+    v = sorted(v[1:]); med = v[len(v) // 2]
+    print("%-66s median %7.1f us  %6.0f TFLOP/s" % (name, med, fl / med / 1e6))
