@@ -8,9 +8,9 @@
 //     dgrad    (autograd of the above):                      A = dy [M][N], B(j=k', kk=n) = W[n][k']
 //     wgrad    :                                             A(i=n, kk=m) = dy[m][n], B(j=k', kk=m) = x[m][k']
 //
-// Tile: 128 x 128 x 16 per 256-thread workgroup; each of the 4 waves owns a 64 x 64
+// Tile: 128 x 128 x 32 per 256-thread workgroup; each of the 4 waves owns a 64 x 64
 // sub-tile (2 x 2 MFMA 32x32 accumulators).  Operands go through LDS in a k-major image
-// S[k][row] (row stride 132 floats) so that both MFMA operand reads are conflict-free
+// S[k][row] (row stride 129 / 132 floats, see LDS_LD) so that both MFMA operand reads are conflict-free
 // ds_read_b32 across 32 consecutive banks; global loads follow whichever index is
 // contiguous in memory and are prefetched into registers one tile ahead.
 #include "codae_common.h"
@@ -18,19 +18,24 @@
 namespace codae {
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16, LD = 132, NT = 256;
+constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
+// LDS row stride of a k-major operand image S[k][row].  Stored from a k-contiguous operand (KC: each lane scatters
+// the 4 k-values of its row): 129 = 1 mod 32 puts the 4 rows x 8 k-groups of a 32-lane store on 32 different banks
+// (132 gave 2-way conflicts: PMC SQ_LDS_BANK_CONFLICT 25 % of LDS cycles in the forward form).  Stored from a
+// row-contiguous operand (float4 along the row): 132 keeps those stores 16-byte aligned.
+template <bool KC> constexpr int LDS_LD = KC ? 129 : 132;
 
-// Load a 128(rows) x 16(k) tile into 8 registers per thread.
-//   KC : element(r,k) = P[r*rs + k]      thread -> row (t>>2)+64p, k 4*(t&3)..+3
-//   !KC: element(r,k) = P[k*ks + r]      thread -> k (t>>5)+8p,  rows 4*(t&31)..+3
+// Load a 128(rows) x 32(k) tile into 16 registers per thread.
+//   KC : element(r,k) = P[r*rs + k]      thread -> row (t>>3)+32p, k 4*(t&7)..+3          (p = 0..3)
+//   !KC: element(r,k) = P[k*ks + r]      thread -> k (t>>5)+8p,   rows 4*(t&31)..+3
 template <bool KC>
-__device__ __forceinline__ void load_tile(float (&reg)[8], const float* __restrict__ P, int64_t rs, int64_t ks,
+__device__ __forceinline__ void load_tile(float (&reg)[16], const float* __restrict__ P, int64_t rs, int64_t ks,
                                           int r0, int k0, int R, int K, bool vec_ok, int t) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < 4; ++p) {
         if constexpr (KC) {
-            const int r = r0 + (t >> 2) + 64 * p;
-            const int k = k0 + 4 * (t & 3);
+            const int r = r0 + (t >> 3) + 32 * p;
+            const int k = k0 + 4 * (t & 7);
             const float* src = P + (int64_t)r * rs + k;
             if (r < R && vec_ok && k + 3 < K) {
                 const float4 v = *reinterpret_cast<const float4*>(src);
@@ -55,12 +60,13 @@ __device__ __forceinline__ void load_tile(float (&reg)[8], const float* __restri
 }
 
 template <bool KC>
-__device__ __forceinline__ void store_tile(float* S, const float (&reg)[8], int t) {
+__device__ __forceinline__ void store_tile(float* S, const float (&reg)[16], int t) {
+    constexpr int LD = LDS_LD<KC>;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < 4; ++p) {
         if constexpr (KC) {
-            const int r = (t >> 2) + 64 * p;
-            const int k = 4 * (t & 3);
+            const int r = (t >> 3) + 32 * p;
+            const int k = 4 * (t & 7);
 #pragma unroll
             for (int c = 0; c < 4; ++c) S[(k + c) * LD + r] = reg[4 * p + c];
         } else {
@@ -74,9 +80,10 @@ __device__ __forceinline__ void store_tile(float* S, const float (&reg)[8], int 
 
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmF32 g, bool a_vec, bool b_vec) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * BK * LD];
+    constexpr int LDA = LDS_LD<A_KC>, LDB = LDS_LD<B_KC>;
+    __shared__ __attribute__((aligned(16))) float smem[BK * 132 * 2];
     float* As = smem;
-    float* Bs = smem + BK * LD;
+    float* Bs = smem + BK * 132;
 
     const int t = threadIdx.x;
     const int lane = t & 63, w = t >> 6;
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmF32 g, bool a_vec, boo
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    float ra[8], rb[8];
+    float ra[16], rb[16];
     load_tile<A_KC>(ra, g.A, g.a_rs, g.a_ks, i0, 0, g.M, g.K, a_vec, t);
     load_tile<B_KC>(rb, g.B, g.b_rs, g.b_ks, j0, 0, g.N, g.K, b_vec, t);
 
@@ -108,10 +115,10 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmF32 g, bool a_vec, boo
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             const int kr = 2 * kk + kh;
-            const float a0 = As[kr * LD + 64 * wr + li];
-            const float a1 = As[kr * LD + 64 * wr + 32 + li];
-            const float b0 = Bs[kr * LD + 64 * wc + li];
-            const float b1 = Bs[kr * LD + 64 * wc + 32 + li];
+            const float a0 = As[kr * LDA + 64 * wr + li];
+            const float a1 = As[kr * LDA + 64 * wr + 32 + li];
+            const float b0 = Bs[kr * LDB + 64 * wc + li];
+            const float b1 = Bs[kr * LDB + 64 * wc + 32 + li];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
