@@ -32,7 +32,14 @@
 extern "C" {
 #endif
 
-#define CODAE_ABI_VERSION 1
+/* Bumped on EVERY change of a struct layout, an enum value or a function signature below.
+ *   1: round 1 as first published (9-field codae_buffers)
+ *   2: codae_buffers.shadow_wt, CODAE_S_ADAM_STEP / CODAE_S_COUNT 80, codae_struct_sizes, codae_reload_env,
+ *      codae_train_step_graph, codae_step_backward_async, codae_side_stream, codae_join, codae_profile_stride
+ *   3: codae_chain_*, CODAE_K_* additions, codae_reduce_* (this round; see the entries' comments)
+ * The binding must refuse a library whose codae_abi_version() differs and must check its own struct sizes against
+ * codae_struct_sizes() at load (mui-deepautoencoder_amd/codae/hip/__init__.py does both). */
+#define CODAE_ABI_VERSION 3
 
 enum {
     CODAE_OK = 0,
@@ -66,7 +73,8 @@ typedef struct {
     int64_t n_param;        /* elements of the flat fp32 parameter vector (with padding) */
     int64_t n_weight;       /* elements of the flat bf16 weight shadow (BF16 mode, else 0) */
     int64_t act_bytes;      /* activation workspace */
-    int64_t dact_bytes;     /* activation-gradient workspace (two ping-pong buffers) */
+    int64_t dact_bytes;     /* activation-gradient workspace: min(n_layers + 1, 16) buffers (at least 3), one per layer
+                               so that the two backward streams never wait for each other; deeper stacks rotate */
     int64_t slab_bytes;     /* split-K partial slabs for the weight-gradient GEMM (BF16 mode) */
     int32_t n_scalars;      /* doubles in the scalar block (CODAE_S_*) */
 } codae_sizes;
@@ -129,6 +137,16 @@ typedef struct {
 
 const char* codae_last_error(void);
 int codae_abi_version(void);
+/* sizeof() of the structs above as THIS library was compiled, then CODAE_S_COUNT and CODAE_K_COUNT:
+ * out[0..6] = {codae_spec, codae_sizes, codae_buffers, codae_batch, codae_hyper, CODAE_S_COUNT, CODAE_K_COUNT}.
+ * A binding compares them with its own declarations before the first call (a short codae_buffers would make the
+ * engine read shadow_wt past the caller's struct). */
+#define CODAE_N_STRUCTS 7
+int codae_struct_sizes(int32_t* out, int32_t capacity);
+/* The CODAE_* tuning / ablation environment variables (CODAE_GEMM_TILE, CODAE_SINGLE_STREAM, CODAE_NO_FUSED_LOSS ...)
+ * are read when the library is first used and at every codae_create, never on the launch path; a caller that
+ * changes one and wants the stand-alone GEMM entry points to see it calls this. */
+int codae_reload_env(void);
 
 /* ---- handle ------------------------------------------------------------- */
 int codae_create(const codae_spec* spec, codae_handle* out);
@@ -164,9 +182,6 @@ int codae_step_backward(codae_handle h, const codae_buffers* bufs, int32_t B, in
                         int32_t layer_hi, void* stream);
 /* global grad norm -> clip -> Adam -> bf16 shadow refresh (:212-215) */
 int codae_step_update(codae_handle h, const codae_buffers* bufs, const codae_hyper* hyper, void* stream);
-/* Make `stream` wait for everything the engine still has in flight on its own streams (the per-layer Adam
- * kernels of the last update run beside the next forward).  Call before reading parameters, Adam state or
- * gradients from another stream / the host. */
 /* codae_train_step replayed from a hipGraph: the first call (and any call whose batch shape / pointers / hyper-
  * parameters differ from the captured ones) captures the whole step - both streams of the backward included - and
  * instantiates it; every call then costs one scalar write (Adam's step count, kept in device memory because kernel
@@ -187,6 +202,9 @@ int codae_step_backward_async(codae_handle h, const codae_buffers* bufs, int32_t
 /* The stream the weight-gradient GEMMs and slab reduces run on (created on first use); NULL when the engine runs
  * everything on the caller's stream (CODAE_SINGLE_STREAM). Owned by the handle. */
 int codae_side_stream(codae_handle h, void** stream_out);
+/* Make `stream` wait for everything the engine still has in flight on its side stream (weight-gradient GEMMs and
+ * slab reduces of a backward issued with codae_step_backward_async).  Call before anything on `stream`, another
+ * stream or the host reads the weight gradients; codae_step_update does so itself. */
 int codae_join(codae_handle h, void* stream);
 /* all three, single GPU */
 int codae_train_step(codae_handle h, const codae_buffers* bufs, const codae_batch* batch,

@@ -14,7 +14,10 @@ LIB_PATH = os.environ.get("CODAE_HIP_LIB") or os.path.join(_HERE, "libcodae_hip.
 PREC_F32 = 0
 PREC_BF16 = 1
 
-S_SQ_FULL, S_SQ_PARTIAL, S_GRAD_SQ, S_LAST_LOSS, S_STEP_SQ, S_GRAD_SQ_SLOTS, S_N_SLOTS, S_COUNT = 0, 1, 2, 3, 4, 8, 64, 72
+ABI_VERSION = 3
+# CODAE_S_* of include/codae_hip.h (tests/test_host_logic.py parses the header and compares)
+S_SQ_FULL, S_SQ_PARTIAL, S_GRAD_SQ, S_LAST_LOSS, S_STEP_SQ, S_CLIP_COEF = 0, 1, 2, 3, 4, 5
+S_GRAD_SQ_SLOTS, S_N_SLOTS, S_ADAM_STEP, S_COUNT = 8, 64, 72, 80
 KERNEL_CLASSES = ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "loss", "gather", "sumsq", "adam", "slab_reduce")
 
 
@@ -60,6 +63,8 @@ _P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 PROTOTYPES = {
     "codae_last_error": (C.c_char_p, []),
     "codae_abi_version": (C.c_int, []),
+    "codae_struct_sizes": (C.c_int, [C.POINTER(C.c_int32), _I32]),
+    "codae_reload_env": (C.c_int, []),
     "codae_create": (C.c_int, [C.POINTER(Spec), C.POINTER(_P)]),
     "codae_destroy": (C.c_int, [_P]),
     "codae_get_sizes": (C.c_int, [_P, C.POINTER(Sizes)]),
@@ -116,10 +121,33 @@ def lib():
         fn = getattr(handle, name)
         fn.restype = res
         fn.argtypes = args
-    if handle.codae_abi_version() != 1:
-        raise HipError("libcodae_hip.so ABI version mismatch")
+    if handle.codae_abi_version() != ABI_VERSION:
+        raise HipError("libcodae_hip.so ABI version %d, this binding is written for %d: rebuild the library"
+                       % (handle.codae_abi_version(), ABI_VERSION))
+    check_struct_sizes(handle)
     _lib = handle
     return _lib
+
+
+def struct_sizes_expected():
+    """What this binding declares, in codae_struct_sizes() order."""
+    return [C.sizeof(Spec), C.sizeof(Sizes), C.sizeof(Buffers), C.sizeof(Batch), C.sizeof(Hyper), S_COUNT,
+            len(KERNEL_CLASSES)]
+
+
+def check_struct_sizes(handle):
+    """A ctypes struct shorter than the library's makes the engine read past the caller's memory
+    (codae_buffers gained shadow_wt in ABI 2): compare every layout before the first call."""
+    n = 7
+    got = (C.c_int32 * n)()
+    rc = handle.codae_struct_sizes(got, n)
+    if rc != 0:
+        raise HipError("codae_struct_sizes failed (%d)" % rc)
+    want = struct_sizes_expected()
+    names = ("codae_spec", "codae_sizes", "codae_buffers", "codae_batch", "codae_hyper", "CODAE_S_COUNT", "CODAE_K_COUNT")
+    bad = ["%s: library %d, binding %d" % (nm, g, w) for nm, g, w in zip(names, list(got), want) if g != w]
+    if bad:
+        raise HipError("libcodae_hip.so and its ctypes binding disagree: " + "; ".join(bad))
 
 
 def check(rc):

@@ -62,7 +62,9 @@ class DaeEngine:
             self.dacts = torch.zeros(max(int(sz.dact_bytes), 16), dtype=torch.uint8, device=device)
             self.slabs = (torch.zeros(int(sz.slab_bytes), dtype=torch.uint8, device=device)
                           if sz.slab_bytes > 0 else None)
-            self.scalars = torch.zeros(S_COUNT, dtype=torch.float64, device=device)
+            if int(sz.n_scalars) != S_COUNT:
+                raise HipError("library reports %d scalars, binding expects %d" % (int(sz.n_scalars), S_COUNT))
+            self.scalars = torch.zeros(int(sz.n_scalars), dtype=torch.float64, device=device)
         self.bufs = Buffers(ptr(self._params), ptr(self.grads), ptr(self.adam_m), ptr(self.adam_v), ptr(self.shadow),
                             ptr(self.acts), ptr(self.dacts), ptr(self.slabs), ptr(self.scalars), ptr(self.shadow_t))
         self.w_off, self.b_off = [], []

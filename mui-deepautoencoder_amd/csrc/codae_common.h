@@ -70,6 +70,20 @@ __device__ __forceinline__ float clamp_below(float x, float floor) {
 
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
+// CODAE_* tuning / ablation variables, read ONCE (library load, codae_create, codae_reload_env): nothing on the
+// launch path calls getenv (round 1 did, ~30 times per step)
+struct EnvToggles {
+    int gemm_tile = -1;          // CODAE_GEMM_TILE s|b|p|q|c|w -> 0..5, -1 = automatic
+    int gemm_dbg = 0;            // CODAE_GEMM_DBG timing-only ablation builds of the forward form
+    bool gemm_dbg8 = false;      // CODAE_GEMM_DBG8: ablations on the 8-wave form
+    int wgrad_splitk = 0;        // CODAE_WGRAD_SPLITK > 0 forces the split
+    bool side_priority_set = false; int side_priority = 0;   // CODAE_SIDE_PRIORITY
+    bool no_wt = false, single_stream = false, tail_on_side = false, no_fused_loss = false, flat_adam = false,
+         no_fused_norm = false, no_chain = false;
+};
+const EnvToggles& env();
+void env_reload();
+
 // ---- generic exact-fp32 GEMM (gemm_f32.hip) --------------------------------
 // C[i][j] = epilogue( sum_k A(i,k) * B(j,k) ), A(i,k) = A[i*a_rs + k*a_ks], B(j,k) = B[j*b_rs + k*b_ks]
 struct GemmF32 {

@@ -20,6 +20,35 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static EnvToggles g_env;
+static bool g_env_loaded = false;
+
+void env_reload() {
+    EnvToggles e;
+    if (const char* t = getenv("CODAE_GEMM_TILE")) {
+        switch (t[0]) { case 's': e.gemm_tile = 0; break; case 'b': e.gemm_tile = 1; break; case 'p': e.gemm_tile = 2; break;
+                        case 'q': e.gemm_tile = 3; break; case 'c': e.gemm_tile = 4; break; case 'w': e.gemm_tile = 5; break; default: break; }
+    }
+    if (const char* d = getenv("CODAE_GEMM_DBG")) e.gemm_dbg = atoi(d);
+    e.gemm_dbg8 = getenv("CODAE_GEMM_DBG8") != nullptr;
+    if (const char* k = getenv("CODAE_WGRAD_SPLITK")) e.wgrad_splitk = atoi(k) > 0 ? atoi(k) : 0;
+    if (const char* pr = getenv("CODAE_SIDE_PRIORITY")) { e.side_priority_set = true; e.side_priority = atoi(pr); }
+    e.no_wt = getenv("CODAE_NO_WT") != nullptr;
+    e.single_stream = getenv("CODAE_SINGLE_STREAM") != nullptr;
+    e.tail_on_side = getenv("CODAE_TAIL_ON_SIDE") != nullptr;
+    e.no_fused_loss = getenv("CODAE_NO_FUSED_LOSS") != nullptr;
+    e.flat_adam = getenv("CODAE_FLAT_ADAM") != nullptr;
+    e.no_fused_norm = getenv("CODAE_NO_FUSED_NORM") != nullptr;
+    e.no_chain = getenv("CODAE_NO_CHAIN") != nullptr;
+    g_env = e;
+    g_env_loaded = true;
+}
+
+const EnvToggles& env() {
+    if (!g_env_loaded) env_reload();
+    return g_env;
+}
+
 }  // namespace codae
 
 using namespace codae;
@@ -66,6 +95,7 @@ struct codae_engine {
     mutable std::vector<int> prof_kind;
     mutable std::vector<int> prof_count;    // launches covered by the record (a GroupScope spans several)
     mutable bool prof_group = false;        // inside a GroupScope of the forward class: no per-launch pairs
+    EnvToggles cfg;                         // the CODAE_* toggles as they stood at codae_create
     int esize() const { return prec == CODAE_PREC_BF16 ? 2 : 4; }
     int rows_for(int B) const { return prec == CODAE_PREC_BF16 ? (int)round_up(B, 64) : B; }
 };
@@ -120,11 +150,10 @@ struct GroupScope {
 // K-slices that the output tiles cover the chip once (256 x 192 tiles), or ~2 workgroups per CU
 // with the 128 x 128 tile when the big one cannot fill it.  Must agree with gemm_bf16_tile_big.
 int choose_split_k(int N, int K, int rows) {
-    const char* env = getenv("CODAE_WGRAD_SPLITK");
     const int kt = rows / 64;
     int s;
-    if (env && atoi(env) > 0) {
-        s = atoi(env);
+    if (env().wgrad_splitk > 0) {
+        s = env().wgrad_splitk;
     } else {
         const int tiles_big = ((N + 255) / 256) * ((K + 191) / 192);
         s = (256 + tiles_big / 2) / tiles_big;
@@ -227,7 +256,7 @@ int run_dgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, fl
     if (e->prec == CODAE_PREC_BF16) {
         GemmBf16 g{};
         g.A = reinterpret_cast<const bf16_t*>(dact_ptr(e, b, l)); g.lda = N; g.a_mode = OP_KC;
-        if (b->shadow_wt != nullptr && l >= 1 && getenv("CODAE_NO_WT") == nullptr) {
+        if (b->shadow_wt != nullptr && l >= 1 && !e->cfg.no_wt) {
             // dx[m][k] = sum_n dy[m][n] Wt[k][n]: both operands k-contiguous -> the forward-form kernel
             g.B = reinterpret_cast<const bf16_t*>(b->shadow_wt) + e->w_off[l]; g.ldb = N; g.b_mode = OP_KC;
         } else {
@@ -291,7 +320,7 @@ int ensure_side_stream(const codae_engine* h) {
     // high-priority ones; and the dgrad chain (critical path, caller's stream) is dispatched first.
     int prio_least = 0, prio_greatest = 0;
     CODAE_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    const int prio = getenv("CODAE_SIDE_PRIORITY") ? atoi(getenv("CODAE_SIDE_PRIORITY")) : prio_least;
+    const int prio = h->cfg.side_priority_set ? h->cfg.side_priority : prio_least;
     CODAE_HIP_CHECK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio));
     CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
     CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
@@ -323,7 +352,7 @@ int join_side(const codae_engine* h, hipStream_t s) {
 int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi, float* dx, bool step_mode,
                    hipStream_t s, bool join = true) {
     const int rows = h->rows_for(B);
-    const bool dual = getenv("CODAE_SINGLE_STREAM") == nullptr;
+    const bool dual = !h->cfg.single_stream;
     if (dual) {
         int rc = ensure_side_stream(h);
         if (rc) return rc;
@@ -336,7 +365,7 @@ int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi
         int rc;
         if (!dual) {
             rc = run_wgrad(h, b, l, rows, s);
-        } else if (join && step_mode && l == 0 && hi - lo >= 3 && getenv("CODAE_TAIL_ON_SIDE") == nullptr) {
+        } else if (join && step_mode && l == 0 && hi - lo >= 3 && !h->cfg.tail_on_side) {
             // tail: the side stream still owes wgrad_1 when the dgrad chain ends, and the caller's stream has
             // nothing left to do: the last weight gradient runs here (third slab buffer), beside wgrad_1
             rc = run_wgrad(h, b, l, rows, s, 2);
@@ -377,6 +406,23 @@ extern "C" {
 const char* codae_last_error(void) { return g_err; }
 int codae_abi_version(void) { return CODAE_ABI_VERSION; }
 
+int codae_reload_env(void) {
+    env_reload();
+    return CODAE_OK;
+}
+
+int codae_struct_sizes(int32_t* out, int32_t capacity) {
+    CODAE_REQUIRE(out != nullptr && capacity >= CODAE_N_STRUCTS, "codae_struct_sizes: need room for %d entries", CODAE_N_STRUCTS);
+    out[0] = (int32_t)sizeof(codae_spec);
+    out[1] = (int32_t)sizeof(codae_sizes);
+    out[2] = (int32_t)sizeof(codae_buffers);
+    out[3] = (int32_t)sizeof(codae_batch);
+    out[4] = (int32_t)sizeof(codae_hyper);
+    out[5] = CODAE_S_COUNT;
+    out[6] = CODAE_K_COUNT;
+    return CODAE_OK;
+}
+
 int codae_create(const codae_spec* spec, codae_handle* out) {
     CODAE_REQUIRE(spec && out, "codae_create: null argument");
     CODAE_REQUIRE(spec->n_layers > 0 && spec->n_layers <= 64, "codae_create: n_layers %d", spec->n_layers);
@@ -395,7 +441,9 @@ int codae_create(const codae_spec* spec, codae_handle* out) {
             }
         }
     }
+    env_reload();                 // the one place (besides library load / codae_reload_env) the CODAE_* variables are read
     codae_engine* e = new codae_engine();
+    e->cfg = env();
     e->L = spec->n_layers;
     e->prec = spec->precision;
     e->max_batch = spec->max_batch;
@@ -603,7 +651,7 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
     if (rc) return rc;
     float* y = out_y ? out_y : reinterpret_cast<float*>(act_ptr(h, b, L));
     // bf16 training step: the loss is folded into the last forward GEMM's epilogue (y never stored)
-    const bool fuse_loss = bf && hyper != nullptr && out_y == nullptr && getenv("CODAE_NO_FUSED_LOSS") == nullptr;
+    const bool fuse_loss = bf && hyper != nullptr && out_y == nullptr && !h->cfg.no_fused_loss;
     GroupScope fwd_group(h, CODAE_K_GEMM_FWD, s);       // the plain forward launches of this step, back to back
     for (int l = 0; l < L; ++l) {
         const bool last = (l == L - 1);
@@ -676,7 +724,7 @@ int codae_step_backward_async(codae_handle h, const codae_buffers* b, int32_t B,
 int codae_side_stream(codae_handle h, void** out) {
     CODAE_REQUIRE(h && out, "codae_side_stream: null argument");
     *out = nullptr;
-    if (getenv("CODAE_SINGLE_STREAM") != nullptr) return CODAE_OK;      // everything runs on the caller's stream
+    if (h->cfg.single_stream) return CODAE_OK;      // everything runs on the caller's stream
     int rc = ensure_side_stream(h);
     if (rc) return rc;
     *out = h->side;
@@ -713,7 +761,7 @@ static int update_impl(codae_handle h, const codae_buffers* b, const codae_hyper
     // slowed those GEMMs from 46.8 to 56.9 us each and the step from 1.76 to 1.84 ms.)
     const double* step_dev = h->capturing ? b->scalars + CODAE_S_ADAM_STEP : nullptr;
     ProfScope prof(h, CODAE_K_ADAM, s);
-    if (h->prec == CODAE_PREC_BF16 && b->shadow_wt != nullptr && h->L <= 64 && getenv("CODAE_FLAT_ADAM") == nullptr) {
+    if (h->prec == CODAE_PREC_BF16 && b->shadow_wt != nullptr && h->L <= 64 && !h->cfg.flat_adam) {
         // one tiled pass: p, m, v, the bf16 shadow and the transposed shadow of every layer that has a data gradient
         return launch_clip_adam_tiled(b->params, b->grads, b->adam_m, b->adam_v, hyper, b->scalars + CODAE_S_GRAD_SQ, shadow,
                                       reinterpret_cast<bf16_t*>(b->shadow_wt), h->L, h->w_off.data(), h->out.data(), h->in.data(),
@@ -741,7 +789,7 @@ int codae_train_step(codae_handle h, const codae_buffers* b, const codae_batch* 
     // single GPU: nothing happens to the gradients between backward and update, so the norm can be
     // gathered while the split-K slabs are reduced (finish_loss zeroed GRAD_SQ before the backward)
     const int rows = h->rows_for(batch->B);
-    bool all_slabbed = h->prec == CODAE_PREC_BF16 && hyper->max_grad_norm > 0.f && getenv("CODAE_NO_FUSED_NORM") == nullptr;
+    bool all_slabbed = h->prec == CODAE_PREC_BF16 && hyper->max_grad_norm > 0.f && !h->cfg.no_fused_norm;
     for (int l = 0; l < h->L && all_slabbed; ++l)
         if ((h->split_k[l] <= rows / 64 ? h->split_k[l] : rows / 64) <= 1) all_slabbed = false;
     h->norm_in_backward = all_slabbed;
@@ -768,7 +816,7 @@ int codae_train_step_graph(codae_handle h, const codae_buffers* b, const codae_b
         if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
         int rc = check_common(h, b, batch->B);
         if (rc) return rc;
-        if (getenv("CODAE_SINGLE_STREAM") == nullptr) {
+        if (!h->cfg.single_stream) {
             rc = ensure_side_stream(h);                      // (no stream / event creation inside the capture)
             if (rc) return rc;
         }

@@ -525,12 +525,7 @@ bool gemm_bf16_supported(int M, int N, int K) {
 // (its operand traffic per flop is 1.7x lower than the 128 x 128 tile's, which is what bounds
 // the small tile: ~39 TB/s of L2 reads at full MFMA rate); else 128 x 128 / 4 waves.
 int gemm_bf16_tile_big(int M, int N, int split_k, bool k_strided = false) {
-    const char* env = getenv("CODAE_GEMM_TILE");
-    if (env && env[0] == 's') return 0;
-    if (env && env[0] == 'b') return 1;
-    if (env && env[0] == 'p') return 2;
-    if (env && env[0] == 'q') return 3;
-    if (env && env[0] == 'c') return 4;
+    if (env().gemm_tile >= 0) return env().gemm_tile;
     const int64_t big = (int64_t)((M + 255) / 256) * ((N + 191) / 192) * split_k;
     // measured (tools/bench_gemm.py, 8192 x 1536 x 1536, us): tile            s     b     c     q
     //   forward (KC x KC)                                                  46.3  38.4  40.2  37.0
@@ -565,7 +560,7 @@ int gemm_bf16(const GemmBf16& g, hipStream_t s) {
                       "gemm_bf16: mask table must be 8-byte aligned");
         CODAE_REQUIRE((reinterpret_cast<uintptr_t>(g.loss.data) & 15) == 0, "gemm_bf16: dataset must be 16-byte aligned");
     }
-    if (const char* d = getenv("CODAE_GEMM_DBG")) { GemmBf16 g2 = g; g2.dbg = atoi(d); if (g2.dbg) return gemm_bf16_pipe(g2, 0, s); }
+    if (env().gemm_dbg) { GemmBf16 g2 = g; g2.dbg = env().gemm_dbg; return gemm_bf16_pipe(g2, 0, s); }
     if (g.loss.enabled) {
         const int t = gemm_bf16_tile_big(g.M, g.N, 1);
         if (t) return launch_cfg<256, 192, 4, 2>(g, s);

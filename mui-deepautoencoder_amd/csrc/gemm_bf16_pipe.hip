@@ -555,7 +555,7 @@ template <int DBG>
 int launch_dbg(const GemmBf16& g, hipStream_t s) {
     constexpr int BM = 256, BN = 192;
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-    if (getenv("CODAE_GEMM_DBG8"))   // the 8-wave form
+    if (env().gemm_dbg8)   // the 8-wave form
         hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, 4, 2, 6, OP_KC, OP_KC, false, DBG>), dim3(tiles_m * tiles_n), dim3(512), 0, s, g,
                            tiles_n, tiles_m * tiles_n, g.K / BK);
     else

@@ -124,7 +124,7 @@ def _state_arrays(prefix, d):
     return {prefix + k.replace(".", "__"): v for k, v in d.items()}
 
 
-def make_embedding(name, seed, N, S, E, z, nb_in, nb_out, batch, epochs, lr, wd):
+def make_embedding(name, seed, N, S, E, z, nb_in, nb_out, batch, epochs, lr, wd, store_adam=True):
     import torch
     import yaml
     cats = ["top", "bottom", "shoe", "bag", "hat", "scarf"][:S]
@@ -191,9 +191,10 @@ def make_embedding(name, seed, N, S, E, z, nb_in, nb_out, batch, epochs, lr, wd)
     for i, gr in enumerate(cap.first_grads):
         out["grad0__%d" % i] = gr
     st = opt.state_dict()["state"]
-    for i in sorted(st):
-        out["adam_m__%d" % i] = st[i]["exp_avg"].numpy()
-        out["adam_v__%d" % i] = st[i]["exp_avg_sq"].numpy()
+    if store_adam:       # (the wide fixtures keep the files small: Adam moments are pinned by the 48-wide ones)
+        for i in sorted(st):
+            out["adam_m__%d" % i] = st[i]["exp_avg"].numpy()
+            out["adam_v__%d" % i] = st[i]["exp_avg_sq"].numpy()
     out["adam_step"] = np.asarray(float(st[0]["step"]))
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print("wrote", name, "steps", len(cap.losses), "ftl", book["ftl"], "rl", book["rl"])
@@ -288,5 +289,12 @@ if __name__ == "__main__":
     # tapered stack (z < io): 48->48->40->32->24->16 | 16->24->32->40->48->48
     make_embedding("embedding_taper", seed=4321, N=300, S=3, E=16, z=16, nb_in=4, nb_out=4,
                    batch=50, epochs=2, lr=1e-3, wd=1e-4)
+    # Widths that are multiples of 64, so the bf16 (throughput) engine can replay a REFERENCE run too:
+    # embedding.yaml's topology (4+4, z = io) at 3 slots x 64: 10 x Linear(192,192), 4 epochs of 9 steps
+    make_embedding("embedding_wide_square", seed=2468, N=400, S=3, E=64, z=192, nb_in=4, nb_out=4,
+                   batch=32, epochs=4, lr=1e-3, wd=1e-4, store_adam=False)
+    # taper 192->192->128->64 | 64->128->192->192
+    make_embedding("embedding_wide_taper", seed=8642, N=400, S=3, E=64, z=64, nb_in=2, nb_out=2,
+                   batch=32, epochs=4, lr=1e-3, wd=1e-4, store_adam=False)
     # abalone schema, --nb_missing 2 (45 augmentation runs per epoch)
     make_abalone("abalone_k2", seed=99, N=300, batch=64, epochs=1, lr=5e-4, wd=1e-6, nb_missing=2)

@@ -119,10 +119,13 @@ SHAPES_BF16 = [(128, 128, 64), (64, 64, 64), (200, 192, 128), (256, 384, 384), (
 
 
 @pytest.fixture(params=["s", "b", "c", "p", "q"], ids=["tile128x128", "tile256x192", "tile128x192x2", "pipe256x192w4", "pipe256x192w8"])
-def tile(request, monkeypatch):
-    """force the small / big workgroup tile of the bf16 GEMM (CODAE_GEMM_TILE is read per launch)"""
+def tile(request, monkeypatch, hip):
+    """force the small / big workgroup tile of the bf16 GEMM (the library reads CODAE_GEMM_TILE at codae_reload_env)"""
     monkeypatch.setenv("CODAE_GEMM_TILE", request.param)
-    return request.param
+    hip.lib().codae_reload_env()
+    yield request.param
+    monkeypatch.delenv("CODAE_GEMM_TILE", raising=False)
+    hip.lib().codae_reload_env()
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES_BF16)

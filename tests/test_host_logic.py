@@ -25,7 +25,60 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in sorted(declared) if not hasattr(lib, n)]
     assert not missing, missing
     assert declared == set(hip.PROTOTYPES), declared ^ set(hip.PROTOTYPES)
-    assert lib.codae_abi_version() == 1
+    assert lib.codae_abi_version() == hip.ABI_VERSION == int(re.search(r"#define CODAE_ABI_VERSION (\d+)", header).group(1))
+
+
+def _header_enum(header, prefix):
+    """{name: value} of the `PREFIX_NAME = value` enumerators of include/codae_hip.h."""
+    return {k: int(v) for k, v in re.findall(r"\b(%s[A-Z0-9_]+)\s*=\s*(-?\d+)" % prefix, header)}
+
+
+def test_binding_constants_match_the_header():
+    """the Python side once hard-coded S_COUNT = 72 against the header's 80 (Adam step slot past the
+    tensor): every CODAE_S_* / CODAE_K_* / CODAE_PREC_* the binding names must equal the header's value."""
+    from codae import hip
+    header = open(os.path.join(ROOT, "include", "codae_hip.h")).read()
+    S = _header_enum(header, "CODAE_S_")
+    for name in ("SQ_FULL", "SQ_PARTIAL", "GRAD_SQ", "LAST_LOSS", "STEP_SQ", "CLIP_COEF", "GRAD_SQ_SLOTS", "N_SLOTS",
+                 "ADAM_STEP", "COUNT"):
+        assert getattr(hip, "S_" + name) == S["CODAE_S_" + name], name
+    assert hip.S_ADAM_STEP < hip.S_COUNT and hip.S_GRAD_SQ_SLOTS + hip.S_N_SLOTS <= hip.S_ADAM_STEP
+    K = _header_enum(header, "CODAE_K_")
+    assert K["CODAE_K_COUNT"] == len(hip.KERNEL_CLASSES)
+    for i, name in enumerate(hip.KERNEL_CLASSES):
+        assert K["CODAE_K_" + name.upper()] == i, name
+    P = _header_enum(header, "CODAE_PREC_")
+    assert (hip.PREC_F32, hip.PREC_BF16) == (P["CODAE_PREC_F32"], P["CODAE_PREC_BF16"])
+
+
+def test_struct_sizes_are_checked_at_load(monkeypatch):
+    """codae_struct_sizes(): the ctypes layouts must equal the library's sizeof()s, and a binding with a short
+    struct (INTEGRATION.md once showed a 9-field codae_buffers) must be refused before any call."""
+    import ctypes as C
+    from codae import hip
+    lib = hip.lib()
+    got = (C.c_int32 * 7)()
+    assert lib.codae_struct_sizes(got, 7) == 0
+    assert list(got) == hip.struct_sizes_expected()
+    assert lib.codae_struct_sizes(got, 3) != 0          # too little room: an error, not an overrun
+
+    class ShortBuffers(C.Structure):
+        _fields_ = hip.Buffers._fields_[:9]
+    monkeypatch.setattr(hip, "Buffers", ShortBuffers)
+    with pytest.raises(hip.HipError, match="codae_buffers"):
+        hip.check_struct_sizes(lib)
+
+
+def test_integration_doc_shows_the_current_binding():
+    """INTEGRATION.md's ctypes snippet is generated from the binding's own field lists."""
+    from codae import hip
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for cls in (hip.Buffers, hip.Batch, hip.Hyper):
+        for name, _ in cls._fields_:
+            assert '"%s"' % name in doc, (cls.__name__, name)
+    header = open(os.path.join(ROOT, "include", "codae_hip.h")).read()
+    for fn in set(re.findall(r"\b(codae_[a-z0-9_]+)\s*\(", header)) - {"codae_engine"}:
+        assert fn in doc, fn
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -43,8 +43,10 @@ tiles = sys.argv[1].split(",") if len(sys.argv) > 1 else ["b", "c", "q"]
 for rnd in range(3):
     for tile in tiles:
         os.environ["CODAE_GEMM_TILE"] = tile
+        hip.lib().codae_reload_env()
         print("tile %s  full batch, 1 stream : %7.1f us per 10 layers" % (tile, timeit(full)))
 if len(sys.argv) > 2:
     for tile in tiles:
         os.environ["CODAE_GEMM_TILE"] = tile
+        hip.lib().codae_reload_env()
         print("tile %s  2 halves, 2 streams  : %7.1f us" % (tile, timeit(lambda: halves([(0, 4096), (4096, 4096)]))))

@@ -28,6 +28,7 @@ res = {(o, c): [] for o in ops for c in cfgs}
 for rnd in range(6):
     for c in cfgs:
         os.environ["CODAE_GEMM_TILE"] = c
+        hip.lib().codae_reload_env()
         for o, f in ops.items():
             for _ in range(3): f()
             torch.cuda.synchronize()

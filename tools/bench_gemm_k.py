@@ -19,6 +19,7 @@ for K in (64, 1536, 3072):
     for c, d in [(c, d) for c in cfgs for d in dbgs]:
         os.environ["CODAE_GEMM_TILE"] = c
         os.environ["CODAE_GEMM_DBG"] = d
+        hip.lib().codae_reload_env()
         ts = []
         for rnd in range(5):
             for _ in range(3): hip.check(L.codae_linear_bf16(hip.ptr(x), hip.ptr(W), hip.ptr(b), hip.ptr(y), 0, M, N, K, 1, st))

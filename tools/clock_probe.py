@@ -18,6 +18,7 @@ os.environ["CODAE_GEMM_TILE"] = "q"
 os.environ["CODAE_GEMM_DBG8"] = "1"
 for d in ("0", "1", "2", "0", "1", "2"):
     os.environ["CODAE_GEMM_DBG"] = d
+    hip.lib().codae_reload_env()
     for _ in range(3):
         hip.check(L.codae_linear_bf16(hip.ptr(x), hip.ptr(W), hip.ptr(b), hip.ptr(y), 0, M, N, K, 0, st))
     torch.cuda.synchronize()

@@ -17,6 +17,7 @@ db = torch.zeros(K, device=dev); dW = torch.empty(N, K, device=dev); slabs = tor
 st = hip.current_stream()
 for c in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["c", "q"]):
     os.environ["CODAE_GEMM_TILE"] = c
+    hip.lib().codae_reload_env()
     for _ in range(3):
         hip.check(L.codae_linear_bf16(hip.ptr(x), hip.ptr(W), hip.ptr(b), hip.ptr(y), 0, M, N, K, 1, st))
         hip.check(L.codae_dgrad_bf16(hip.ptr(dy), hip.ptr(W), hip.ptr(h), hip.ptr(dx), hip.ptr(db), M, N, K, st))
