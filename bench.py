@@ -15,7 +15,9 @@ GEMMs, MSE loss+grad+metric sums, 10 weight-gradient + 9 data-gradient GEMMs, gr
 Adam + bf16 shadow refresh); with N > 1 the gradient buckets are all-reduced over RCCL between
 backward and update, overlapped with the remaining backward GEMMs.
 
-One JSON line on rank 0.  `roofline`: the forward GEMM class (the 3-slot x 512 encoder GEMM), timed
+Presets: --config c2 (3x128, batch 1024), c3 (default: 3x512, batch 8192 = BASELINE.json's metric), c5 (6x1024,
+batch 16384).  One JSON line on rank 0.  `f32_parity` (N = 1, c3 only): the same workload on the exact-fp32 engine
+(the mode the rtol 1e-3 / atol 1e-5 reference replays run in), timed after the bf16 region.  `roofline`: the forward GEMM class (the 3-slot x 512 encoder GEMM), timed
 with hipEvent pairs recorded around every launch of the timed region on the launch stream
 (codae_profile_begin/_end); achieved = 2*M*N*K / mean launch time.  (dgrad and wgrad launches of a
 layer run concurrently on two streams; their overlapping times are listed under by_kernel.)  `cpu_baseline`: the numpy
@@ -38,6 +40,7 @@ for p in (ROOT, os.path.join(ROOT, "mui-deepautoencoder_amd")):
 S, E, BATCH = 3, 512, 8192
 N_IN, N_OUT = 4, 4
 LR, WD, CLIP = 1e-5, 1e-4, 1.0
+CONFIGS = {"c2": (3, 128, 1024), "c3": (3, 512, 8192), "c5": (6, 1024, 16384)}
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_F32_TFLOPS = 157.3
 
@@ -64,7 +67,7 @@ def make_inputs(n_rows, io, slots):
     return data, blank.astype(np.int32)
 
 
-def cpu_baseline(schedule, data, blank, io, slots, budget_s=18.0):
+def cpu_baseline(schedule, data, blank, io, slots, B=BATCH, budget_s=18.0):
     """Time the oracle's training step (numpy, BLAS threads = host cores given to this process)."""
     import numpy as np
     from oracle import dae_oracle as O
@@ -78,7 +81,6 @@ def cpu_baseline(schedule, data, blank, io, slots, budget_s=18.0):
     tr = O.EmbeddingTrainer(params, [r for _, _, r in schedule], LR, WD)
     arch = [{"size": io // slots, "position": s * (io // slots)} for s in range(slots)]
     bm, _, _ = O.corrupter_tables(arch, 1)
-    B = BATCH
     x = data[:B]
     fmask = bm[blank[:B]]
     t0 = time.perf_counter()
@@ -93,8 +95,8 @@ def cpu_baseline(schedule, data, blank, io, slots, budget_s=18.0):
         if t_sum > 2 * budget_s:
             break
     out = {"value": B * n / t_sum, "unit": "samples/s", "cores": int(threads), "kind": "port",
-           "sample": "%d timed steps (1 warm-up) of the numpy oracle step at the same 3x512 / batch %d workload, fp32"
-                     % (n, B),
+           "sample": "%d timed steps (1 warm-up) of the numpy oracle step at the same %dx%d / batch %d workload, fp32"
+                     % (n, slots, io // slots, B),
            "ms_per_step": 1e3 * t_sum / n}
     out["torch_cpu"] = torch_cpu_baseline(schedule, x, fmask, budget_s=8.0)
     return out
@@ -147,16 +149,24 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--slots", type=int, default=S)
-    ap.add_argument("--embedding", type=int, default=E)
-    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS), help="workload preset (SURVEY.md 8d)")
+    ap.add_argument("--slots", type=int, default=None)
+    ap.add_argument("--embedding", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--no-f32-parity", action="store_true", help="skip the exact-fp32 (parity mode) leg")
+    ap.add_argument("--kernel-events-every", type=int, default=4,
+                    help="record per-launch hipEvent pairs in every n-th timed step only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not record per-launch hipEvents in the timed region (roofline then null)")
     ap.add_argument("--buckets", type=int, default=4)
-    ap.add_argument("--all-kernel-events", action="store_true")
+    ap.add_argument("--fwd-events-only", action="store_true", help="time only the forward GEMM class")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (single GPU; no live kernel events)")
     args = ap.parse_args()
+    cs, ce, cb = CONFIGS[args.config]
+    args.slots = cs if args.slots is None else args.slots
+    args.embedding = ce if args.embedding is None else args.embedding
+    args.batch = cb if args.batch is None else args.batch
 
     import numpy as np
     import torch
@@ -227,14 +237,18 @@ def main():
         tr.train_batch(idx_steps[st], run=0)
     barrier()
     kernel_events = not args.no_kernel_events and not args.graph
+    every = max(1, args.kernel_events_every)
     if kernel_events:
         # A hipEvent pair costs 2-4 us of stream time INSIDE the timed region (it breaks back-to-back dispatch).  The
         # forward launches of a step (the class the roofline is quoted on) are dependent, gap-free kernels on one
-        # stream, so the engine brackets the whole run of them with ONE pair and reports elapsed / launches:
-        # ~0.3 % of the step.  --all-kernel-events adds per-launch pairs for the other classes (20 more pairs per
-        # step: ~8 % slower steps).
-        classes = ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "loss") if args.all_kernel_events else ("gemm_fwd",)
-        tr.engine.profile_begin(classes, max_records=32 * args.steps + 64, every=1)
+        # stream, so the engine brackets the whole run of them with ONE pair and reports elapsed / launches.  Every
+        # other class gets a pair per launch; all of it only in every `every`-th step (codae_profile_stride), so the
+        # timed region as a whole is perturbed by ~8 % / every.
+        from codae.hip import KERNEL_CLASSES
+        classes = ("gemm_fwd",) if args.fwd_events_only else KERNEL_CLASSES
+        tr.engine.profile_begin(classes, max_records=64 * (args.steps // every + 2), every=every)
+        if tr.dp is not None:
+            tr.dp.time_waits(every)
     t0 = time.perf_counter()
     for st in range(args.warmup, total_steps):
         tr.train_batch(idx_steps[st], run=0)
@@ -248,6 +262,37 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     loss, gnorm = tr.last_loss_and_grad_norm()
+    dp_info = None
+    if distributed:
+        dp_info = {"rccl_ranks": int(dist.get_world_size()), "backend": dist.get_backend(),
+                   "buckets": [list(b) for b in tr.dp.buckets], "exposed_wait_ms_per_step": tr.dp.wait_report()}
+
+    # exact-fp32 (parity) mode on the same workload: the mode every reference-pinned rtol 1e-3 / atol 1e-5 replay runs in
+    f32_parity = None
+    if (world == 1 and not distributed and args.precision == "bf16" and args.config == "c3" and not args.no_f32_parity
+            and (slots, emb, B) == CONFIGS["c3"] and not args.graph):
+        del tr
+        torch.cuda.empty_cache()
+        tr32 = HipEmbeddingTrainer(schedule, torch.from_numpy(data), torch.from_numpy(table), mask_to_use, LR, WD, CLIP,
+                                   max_batch=B, precision="f32", device=dev)
+        tr32.init_params(seed=0)
+        n32, w32 = 10, 3
+        for st in range(w32):
+            tr32.train_batch(idx_steps[st % total_steps], run=0)
+        torch.cuda.synchronize()
+        t32 = time.perf_counter()
+        for st in range(n32):
+            tr32.train_batch(idx_steps[(w32 + st) % total_steps], run=0)
+        torch.cuda.synchronize()
+        t32 = time.perf_counter() - t32
+        fps32 = flops_per_sample(schedule)
+        f32_parity = {"ms_per_step": 1e3 * t32 / n32, "samples_per_s": B * n32 / t32, "steps": n32, "warmup": w32,
+                      "tflops": fps32 * B * n32 / t32 / 1e12,
+                      "frac_of_157.3TF": fps32 * B * n32 / t32 / (PEAK_F32_TFLOPS * 1e12),
+                      "final_loss": tr32.last_loss_and_grad_norm()[0],
+                      "note": "same workload, CODAE_PREC_F32 engine (v_mfma_f32_32x32x2_f32, exact fp32): the mode the "
+                              "reference replays at rtol 1e-3 / atol 1e-5 run in"}
+        del tr32
 
     if rank == 0:
         fps = flops_per_sample(schedule)
@@ -267,36 +312,48 @@ def main():
                        "mfma_roofline_frac_whole_step": (fps * value / world) / (peak * 1e12)},
             "final_loss": loss, "final_grad_norm": gnorm,
             "host_enqueue_ms_per_step": 1e3 * enqueue_s / args.steps,
+            "f32_parity": f32_parity,
         }
+        if dp_info is not None:
+            out["data_parallel"] = dp_info
         roof = None
         if prof:
             by = {}
-            sampled_steps = args.steps
+            sampled_steps = max(1, args.steps // every)
             gemm_flops = 2.0 * B * io * io
             for name, ms in prof.items():
                 mean_ms = float(np.mean(ms))
                 by[name] = {"launches": len(ms), "mean_ms": mean_ms, "min_ms": float(np.min(ms)),
-                            "tflops": gemm_flops / (mean_ms * 1e-3) / 1e12,
                             "ms_per_step": float(np.sum(ms)) / max(1, sampled_steps), "sampled_steps": sampled_steps}
+                if name in ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "loss"):
+                    by[name]["tflops"] = gemm_flops / (mean_ms * 1e-3) / 1e12
             # ("loss" in the fused bf16 step = the LAST forward GEMM with the MSE loss in its epilogue: GEMM flops
             # plus a gather of the 50 MB target rows, so it is listed apart from the plain forward launches)
             # The forward GEMM class (the "3-slot x 512 encoder GEMM" of BASELINE.json) is the kernel the
             # roofline is quoted on: its launches run alone on the chip.  The dgrad and wgrad launches of one
             # layer run CONCURRENTLY on two streams, so their per-launch event times overlap (by_kernel keeps them).
             dom = "gemm_fwd" if "gemm_fwd" in by else max(by, key=lambda k: by[k]["ms_per_step"])
-            traffic = None
+            # HBM-side bytes per launch of the dominant kernel: an OFFLINE measurement (two rocprofv3 --pmc passes of this
+            # very command, reduced by tools/hbm_traffic.py), keyed by workload + precision; null for any other shape
+            traffic, traffic_src = None, None
+            wkey = "%dx%d_b%d_%s" % (slots, emb, B, args.precision)
             tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if os.path.exists(tfile):
                 try:
-                    traffic = json.load(open(tfile)).get(dom)
+                    tj = json.load(open(tfile))
+                    rec = tj.get("workloads", {}).get(wkey)
+                    if rec is not None and dom in rec:
+                        traffic = rec[dom]
+                        traffic_src = "offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/hbm_traffic.json[%s] (%s)" % (
+                            wkey, rec.get("_source", "?"))
                 except Exception:
                     traffic = None
             roof = {"bound": "mfma", "kernel": dom, "achieved": by[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
-                    "frac": by[dom]["tflops"] / peak, "traffic": traffic,
+                    "frac": by[dom]["tflops"] / peak, "traffic": traffic, "traffic_source": traffic_src,
                     "flops_per_launch": gemm_flops, "by_kernel": by}
         out["roofline"] = roof
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(schedule, data, blank, io, slots)
+            out["cpu_baseline"] = cpu_baseline(schedule, data, blank, io, slots, B)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

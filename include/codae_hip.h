@@ -76,6 +76,7 @@ typedef struct {
     int64_t dact_bytes;     /* activation-gradient workspace: min(n_layers + 1, 16) buffers (at least 3), one per layer
                                so that the two backward streams never wait for each other; deeper stacks rotate */
     int64_t slab_bytes;     /* split-K partial slabs for the weight-gradient GEMM (BF16 mode) */
+    int64_t bias_part_bytes; /* partial column sums of the bias gradients (codae_buffers.bias_parts) */
     int32_t n_scalars;      /* doubles in the scalar block (CODAE_S_*) */
 } codae_sizes;
 
@@ -93,6 +94,10 @@ typedef struct {
     void* shadow_wt;    /* optional (BF16 mode): bf16 TRANSPOSED weights, per layer [in][out] at the same offsets as
                            shadow_w; when present the data-gradient GEMM reads it k-contiguously (forward-form
                            kernel) instead of reading W through transposed LDS reads; n_weight elements */
+    float* bias_parts;  /* bias_part_bytes: every producer of an activation gradient leaves per-row-block partial column
+                           sums here with plain stores; one small kernel per backward call adds them up in a fixed order
+                           into grads' bias block (autograd's bias gradient, train_dae_on_embedding.py:210) - the step has
+                           no float atomics, so the same inputs give the same bits on every run (ABI 3) */
 } codae_buffers;
 
 /* indices into codae_buffers.scalars (device memory, accumulated across calls until zeroed) */
@@ -286,7 +291,8 @@ int codae_wgrad_f32(const float* dy, const float* x, float* dW, float* db, int32
  * y_f32 != 0 -> y is fp32. */
 int codae_linear_bf16(const void* x, const void* W, const float* b, void* y, int32_t y_f32, int32_t M,
                       int32_t N, int32_t K, int32_t relu, void* stream);
-int codae_dgrad_bf16(const void* dy, const void* W, const void* relu_src, void* dx, float* db_prev,
+/* db_prev (optional, [K]) = column sums of the stored dx; needs db_ws: ceil(M / 128) * K floats of scratch */
+int codae_dgrad_bf16(const void* dy, const void* W, const void* relu_src, void* dx, float* db_prev, float* db_ws,
                      int32_t M, int32_t N, int32_t K, void* stream);
 int codae_wgrad_bf16(const void* dy, const void* x, float* dW, void* slabs, int64_t slab_bytes,
                      int32_t M, int32_t N, int32_t K, void* stream);

@@ -36,13 +36,15 @@ class Spec(C.Structure):
 
 class Sizes(C.Structure):
     _fields_ = [("n_param", C.c_int64), ("n_weight", C.c_int64), ("act_bytes", C.c_int64),
-                ("dact_bytes", C.c_int64), ("slab_bytes", C.c_int64), ("n_scalars", C.c_int32)]
+                ("dact_bytes", C.c_int64), ("slab_bytes", C.c_int64), ("bias_part_bytes", C.c_int64),
+                ("n_scalars", C.c_int32)]
 
 
 class Buffers(C.Structure):
     _fields_ = [("params", C.c_void_p), ("grads", C.c_void_p), ("adam_m", C.c_void_p),
                 ("adam_v", C.c_void_p), ("shadow_w", C.c_void_p), ("acts", C.c_void_p),
-                ("dacts", C.c_void_p), ("slabs", C.c_void_p), ("scalars", C.c_void_p), ("shadow_wt", C.c_void_p)]
+                ("dacts", C.c_void_p), ("slabs", C.c_void_p), ("scalars", C.c_void_p), ("shadow_wt", C.c_void_p),
+                ("bias_parts", C.c_void_p)]
 
 
 class Batch(C.Structure):
@@ -96,7 +98,7 @@ PROTOTYPES = {
     "codae_dgrad_f32": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _P]),
     "codae_wgrad_f32": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _P]),
     "codae_linear_bf16": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
-    "codae_dgrad_bf16": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
+    "codae_dgrad_bf16": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
     "codae_wgrad_bf16": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P]),
     "codae_cast_f32_to_bf16": (C.c_int, [_P, _P, _I64, _P]),
     "codae_debug_gemm_timeline": (C.c_int, [_P, _I32]),

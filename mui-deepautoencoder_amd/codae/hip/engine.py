@@ -62,11 +62,14 @@ class DaeEngine:
             self.dacts = torch.zeros(max(int(sz.dact_bytes), 16), dtype=torch.uint8, device=device)
             self.slabs = (torch.zeros(int(sz.slab_bytes), dtype=torch.uint8, device=device)
                           if sz.slab_bytes > 0 else None)
+            # partial column sums of the bias gradients (one small deterministic finish kernel per backward call)
+            self.bias_parts = torch.zeros(max(int(sz.bias_part_bytes) // 4, 16), dtype=torch.float32, device=device)
             if int(sz.n_scalars) != S_COUNT:
                 raise HipError("library reports %d scalars, binding expects %d" % (int(sz.n_scalars), S_COUNT))
             self.scalars = torch.zeros(int(sz.n_scalars), dtype=torch.float64, device=device)
         self.bufs = Buffers(ptr(self._params), ptr(self.grads), ptr(self.adam_m), ptr(self.adam_v), ptr(self.shadow),
-                            ptr(self.acts), ptr(self.dacts), ptr(self.slabs), ptr(self.scalars), ptr(self.shadow_t))
+                            ptr(self.acts), ptr(self.dacts), ptr(self.slabs), ptr(self.scalars), ptr(self.shadow_t),
+                            ptr(self.bias_parts))
         self.w_off, self.b_off = [], []
         for l in range(self.L):
             w, b, s = C.c_int64(), C.c_int64(), C.c_int64()

@@ -100,6 +100,22 @@ class DataParallel:
         # single-GPU box exercise the RCCL path end to end)
         import os
         self.always_reduce = dist.is_initialized() and os.environ.get("CODAE_DP_FORCE_ALLREDUCE") == "1"
+        self._tw_every, self._tw_step, self._tw = 0, 0, []
+
+    # ---- exposed-wait timing (bench.py --gpus N) ------------------------------------------
+    def time_waits(self, every=4):
+        """In every `every`-th step bracket each bucket's wait with a hipEvent pair on the compute stream: the
+        elapsed time is how long the step was held up by that bucket's all-reduce (0 = fully hidden)."""
+        self._tw_every, self._tw_step, self._tw = max(1, int(every)), 0, []
+
+    def wait_report(self):
+        """[mean exposed milliseconds per step] per bucket (last entry: the bias block); synchronises."""
+        if not self._tw:
+            return None
+        import torch
+        torch.cuda.synchronize()
+        n = len(self._tw[0])
+        return [sum(rec[i][0].elapsed_time(rec[i][1]) for rec in self._tw) / len(self._tw) for i in range(n)]
 
     def _weight_span(self, lo, hi):
         # weights of consecutive layers are contiguous in the flat vector
@@ -131,8 +147,23 @@ class DataParallel:
         # bias gradients of layer l are finished by the dgrad of layer l+1: reduce the block last
         works.append(self.dist.all_reduce(eng.grads[eng.b_off[0]:eng.n_param], op=self.dist.ReduceOp.SUM,
                                           group=self.group, async_op=True))
+        timed = False
+        if self._tw_every:
+            self._tw_step += 1
+            timed = self._tw_step % self._tw_every == 0
+        if not timed:
+            for w in works:
+                w.wait()
+            return
+        import torch
+        rec = []
         for w in works:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             w.wait()
+            e1.record()
+            rec.append((e0, e1))
+        self._tw.append(rec)
 
     def train_step(self, batch, hyper, B):
         """forward+loss -> bucketed backward with overlapped all-reduce -> clip+Adam.

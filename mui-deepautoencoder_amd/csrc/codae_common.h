@@ -68,6 +68,15 @@ __device__ __forceinline__ float clamp_below(float x, float floor) {
     return r;
 }
 
+// bias[j .. j+3] (or zeros when there is no bias / j is past N) as ONE unconditional 16-B load from a clamped address:
+// with a branch around it the compiler waits for each of an epilogue's 6 bias loads before issuing the next one
+// (~0.5 us of L2 latency apiece).  `valid`: any readable 16-B aligned address.
+__device__ __forceinline__ float4 load_bias4(const float* __restrict__ bias, const void* valid, int j, int N) {
+    const bool ok = bias != nullptr && j < N;
+    const float4 v = *reinterpret_cast<const float4*>(ok ? bias + j : reinterpret_cast<const float*>(valid));
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 // CODAE_* tuning / ablation variables, read ONCE (library load, codae_create, codae_reload_env): nothing on the
@@ -95,9 +104,11 @@ struct GemmF32 {
     int relu;                // max(v, 0)
     const float* relu_src;   // [M][ld_relu] multiply by (src > 0), or null
     int64_t ld_relu;
-    float* colsum;           // [N] atomicAdd of column sums of the stored values, or null
+    float* colsum_part;      // [ceil(M / 64)][N] column sums of the stored values per 64-row block (plain stores, summed in
+                             // a fixed order by launch_bias_finish: deterministic bias gradients), or null
 };
 int gemm_f32(const GemmF32& g, hipStream_t s);
+inline int gemm_f32_colsum_rows(int M) { return (M + 63) / 64; }
 
 // ---- bf16 MFMA GEMM (gemm_bf16.hip) ----------------------------------------
 enum { OP_KC = 0,  // operand stored [rows][k] (k contiguous)
@@ -127,26 +138,27 @@ struct GemmBf16 {
     const float* bias;
     int relu;
     const bf16_t* relu_src; int64_t ld_relu;
-    float* colsum;
+    float* colsum_part;      // [tiles_m][N] per-tile column sums of the stored values (plain stores; see GemmF32), or null
     int split_k;             // >1: fp32 partial slabs C + z*M*ldc, K range split evenly in BK units
-    LossFuse loss;           // enabled: C receives dy (bf16), colsum the last bias gradient
+    LossFuse loss;           // enabled: C receives dy (bf16), colsum_part the last bias gradient's partial sums
     int dbg;                 // timing-only ablations (CODAE_GEMM_DBG): 1 no LDS-DMA, 2 no MFMA, 4 no epilogue stores
 };
 bool gemm_bf16_supported(int M, int N, int K);
+int gemm_bf16_colsum_rows(const GemmBf16& g);   // rows of colsum_part this launch writes (= its tiles along M)
 int gemm_bf16(const GemmBf16& g, hipStream_t s);
 int gemm_bf16_pipe(const GemmBf16& g, int cfg, hipStream_t s);   // gemm_bf16_pipe.hip
 
 // ---- elementwise / reductions (elementwise.hip) ----------------------------
-// zero_ptr != null: also clears zero_n floats there (the bias-gradient block, ahead of a training step)
-int launch_gather_corrupt(const codae_batch* b, void* out, int out_bf16, hipStream_t s, float* zero_ptr = nullptr,
-                          int64_t zero_n = 0);
+int launch_gather_corrupt(const codae_batch* b, void* out, int out_bf16, hipStream_t s);
 int launch_cast_bf16(const float* src, bf16_t* dst, int64_t n, hipStream_t s);
 int launch_corrupt(const float* x, const float* mask, float* out, int64_t n, hipStream_t s);
 int launch_expand_masks(const int32_t* mask_id, const uint8_t* table, const int32_t* k_of_mask, int B, int io,
                         int k_max, float* masks_out, float* fmask_out, hipStream_t s);
-// y fp32 [B][io]; x gathered from batch; writes dy (fp32 or bf16), metric sums, optional colsum (bias grad)
-int launch_mse_loss(const codae_batch* b, const float* y, void* dy, int dy_bf16, float inv_n, float* colsum,
+// y fp32 [B][io]; x gathered from batch; writes dy (fp32 or bf16), metric sums, optional colsum_part
+// [mse_loss_colsum_rows(B)][io] (partial sums of the last bias gradient, one row per block)
+int launch_mse_loss(const codae_batch* b, const float* y, void* dy, int dy_bf16, float inv_n, float* colsum_part,
                     double* scalars, int want_grad, hipStream_t s);
+int mse_loss_colsum_rows(int B);
 int launch_mse_dense(const float* x, const float* y, const float* fmask, float* dy, int64_t n, float inv_n,
                      double* scalars, hipStream_t s);
 int launch_sumsq(const float* g, int64_t n, double* out, hipStream_t s);
@@ -166,12 +178,24 @@ int launch_clip_adam_tiled(float* p, float* g, float* m, float* v, const codae_h
 int launch_transpose_bf16(const bf16_t* src, bf16_t* dst, int n, const int64_t* off, const int* rows, const int* cols,
                           hipStream_t s);
 int gemm_bf16_timeline(unsigned long long* host_out, int n_wg);   // CODAE_GEMM_DBG=8 stamps
-// sumsq != null: += sum out^2 (slot-scattered) and, with `extra`, += sum extra[0..n_extra)^2
+// sumsq != null: += sum out^2 (slot-scattered)
 int launch_reduce_slabs(const float* slabs, int n_slabs, int64_t slab_stride, float* out, int64_t n, double* sumsq,
-                        hipStream_t s, const float* extra = nullptr, int n_extra = 0);
+                        hipStream_t s);
 int launch_finish_loss(double* scalars, double inv_n, hipStream_t s);
 int launch_cast_f32(const bf16_t* src, float* dst, int64_t n, hipStream_t s);
-// out[n] += sum_m src[m][n]
+// out[n] = sum_m src[m][n], rows added in index order (deterministic; stand-alone primitive)
 int launch_colsum_f32(const float* src, int M, int N, float* out, hipStream_t s);
+// parts[p][n] = sum of rows [64 p, 64 p + 64) of src (first stage of the engine's bias gradient of a dense dy)
+int launch_colsum_parts_f32(const float* src, int M, int N, float* parts, hipStream_t s);
+// Second stage of every bias gradient: out_j[c] = sum_p parts_j[p][c] (p ascending), up to 64 jobs per launch;
+// sumsq != null: += sum out^2 (slot-scattered, clip_grad_norm_)
+struct BiasFinishJobs {
+    int n;
+    const float* parts[64];
+    float* out[64];
+    int rows[64], cols[64];
+    int col_begin[65];       // prefix sum of cols: block -> job lookup
+};
+int launch_bias_finish(const BiasFinishJobs& jobs, double* sumsq, hipStream_t s);
 
 }  // namespace codae

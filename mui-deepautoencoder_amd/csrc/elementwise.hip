@@ -49,9 +49,8 @@ __global__ __launch_bounds__(NT) void gather_corrupt_bf16x8_kernel(const float* 
                                                                    const uint8_t* __restrict__ table, int B, int io,
                                                                    bf16_t* __restrict__ out,
                                                                    const int32_t* __restrict__ mask_to_use, int nb_run,
-                                                                   int run, float* __restrict__ zero_ptr, int64_t zero_n) {
+                                                                   int run) {
     const bool masked = (mask_id != nullptr) || (mask_to_use != nullptr);
-    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < zero_n; e += (int64_t)gridDim.x * NT) zero_ptr[e] = 0.f;
     const int cols = io / 8;
     const int64_t total = (int64_t)B * cols;
     for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < total; e += (int64_t)gridDim.x * NT) {
@@ -85,12 +84,9 @@ __global__ __launch_bounds__(NT) void gather_corrupt_kernel(const float* __restr
                                                             const uint8_t* __restrict__ table, int B, int io,
                                                             void* __restrict__ out,
                                                             const int32_t* __restrict__ mask_to_use, int nb_run,
-                                                            int run, float* __restrict__ zero_ptr, int64_t zero_n) {
+                                                            int run) {
     constexpr int W = VEC ? 4 : 1;
     const bool masked = (mask_id != nullptr) || (mask_to_use != nullptr);
-    // rides along in the first kernel of a training step: clear the bias-gradient block that the later
-    // GEMM epilogues accumulate into with atomics (saves a memset launch in the forward chain)
-    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < zero_n; e += (int64_t)gridDim.x * NT) zero_ptr[e] = 0.f;
     const int cols = io / W;
     const int64_t total = (int64_t)B * cols;
     for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < total; e += (int64_t)gridDim.x * NT) {
@@ -171,12 +167,13 @@ __global__ __launch_bounds__(NT) void expand_masks_kernel(const int32_t* __restr
 }
 
 // ---- a4 + a11: MSELoss(mean) forward/backward + the per-step metric sums --------------------
-// One block owns ROWS consecutive batch rows and sweeps all columns, so that the bias gradient
-// of the last Linear (column sums of dy) costs one atomic per column per block.
+// One block owns ROWS consecutive batch rows and sweeps all columns; the bias gradient of the last
+// Linear (column sums of dy) leaves as one partial-sum row per block (plain stores, added up in block
+// order by bias_finish_kernel: deterministic).
 //   dy = 2 (y - x) * inv_n                          (autograd of train_dae_on_embedding.py:206)
 //   SQ_FULL    += sum (x-y)^2                        (:218-220)
 //   SQ_PARTIAL += sum (1-fmask)(x-y)^2               (:223)
-constexpr int LOSS_ROWS = 32;   // rows per block: each block costs `io` column-sum atomics, so keep blocks few
+constexpr int LOSS_ROWS = 32;   // rows per block = rows per partial column-sum row
 constexpr int LOSS_UNROLL = 8;  // rows in flight per thread
 template <bool VEC, bool DY_BF16>
 __global__ __launch_bounds__(NT) void mse_loss_kernel(const float* __restrict__ data,
@@ -184,7 +181,7 @@ __global__ __launch_bounds__(NT) void mse_loss_kernel(const float* __restrict__ 
                                                       const int32_t* __restrict__ mask_id,
                                                       const uint8_t* __restrict__ table, int B, int io,
                                                       const float* __restrict__ y, void* __restrict__ dy,
-                                                      float inv_n, float* __restrict__ colsum,
+                                                      float inv_n, float* __restrict__ colsum_part,
                                                       double* __restrict__ scalars, int want_grad,
                                                       const int32_t* __restrict__ mask_to_use, int nb_run, int run) {
     __shared__ float red[4];
@@ -242,9 +239,9 @@ __global__ __launch_bounds__(NT) void mse_loss_kernel(const float* __restrict__ 
                 }
             }
         }
-        if (want_grad && colsum) {
+        if (want_grad && colsum_part) {
 #pragma unroll
-            for (int k = 0; k < W; ++k) atomicAdd(&colsum[c + k], cs[k]);
+            for (int k = 0; k < W; ++k) colsum_part[(int64_t)blockIdx.x * io + c + k] = cs[k];
         }
     }
     const float bsq = block_sum(sq, red);
@@ -375,13 +372,9 @@ __global__ __launch_bounds__(NT) void clip_adam_kernel(float* __restrict__ p, co
 // sumsq += sum out[i]^2 so that clip_grad_norm_ needs no second pass over the gradient
 __global__ __launch_bounds__(NT) void reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs,
                                                           int64_t stride, float* __restrict__ out, int64_t n,
-                                                          double* __restrict__ sumsq, const float* __restrict__ extra,
-                                                          int n_extra) {
+                                                          double* __restrict__ sumsq) {
     __shared__ float red[4];
     float sq = 0.f;
-    // the layer's bias gradient (complete before this layer's weight-gradient GEMM started) joins the norm here
-    if (blockIdx.x == 0)
-        for (int e = threadIdx.x; e < n_extra; e += NT) sq += extra[e] * extra[e];
     const int64_t n4 = n / 4;
     for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < n4; e += (int64_t)gridDim.x * NT) {
         float4 a = reinterpret_cast<const float4*>(slabs)[e];
@@ -405,15 +398,49 @@ __global__ __launch_bounds__(NT) void reduce_slabs_kernel(const float* __restric
     }
 }
 
-// out[c] += sum over the block's 64 rows of src[r][c]   (bias gradient of a dense dy)
-__global__ __launch_bounds__(NT) void colsum_f32_kernel(const float* __restrict__ src, int M, int N,
-                                                        float* __restrict__ out) {
+// parts[block][c] = sum over the block's 64 rows of src[r][c]   (bias gradient of a dense dy, first stage)
+__global__ __launch_bounds__(NT) void colsum_parts_f32_kernel(const float* __restrict__ src, int M, int N,
+                                                              float* __restrict__ parts) {
     const int r_begin = blockIdx.x * 64;
     const int r_end = min(M, r_begin + 64);
     for (int c = threadIdx.x; c < N; c += NT) {
         float s = 0.f;
         for (int r = r_begin; r < r_end; ++r) s += src[(int64_t)r * N + c];
-        atomicAdd(&out[c], s);
+        parts[(int64_t)blockIdx.x * N + c] = s;
+    }
+}
+
+// out[c] = sum_r src[r][c], rows in index order, one thread per column (stand-alone primitive: small problems)
+__global__ __launch_bounds__(NT) void colsum_f32_kernel(const float* __restrict__ src, int M, int N,
+                                                        float* __restrict__ out) {
+    const int c = blockIdx.x * NT + threadIdx.x;
+    if (c >= N) return;
+    float s = 0.f;
+    for (int r = 0; r < M; ++r) s += src[(int64_t)r * N + c];
+    out[c] = s;
+}
+
+// Second stage of every bias gradient (and the deterministic replacement of round 1's float atomics): job j's
+// out[c] = parts[0][c] + parts[1][c] + ... in row order; optionally sum out^2 for clip_grad_norm_.
+__global__ __launch_bounds__(NT) void bias_finish_kernel(BiasFinishJobs jobs, double* __restrict__ sumsq) {
+    __shared__ float red[4];
+    const int gc = blockIdx.x * NT + threadIdx.x;            // column in the concatenation of all jobs
+    float sq = 0.f;
+    if (gc < jobs.col_begin[jobs.n]) {
+        int j = 0;
+        while (j + 1 < jobs.n && gc >= jobs.col_begin[j + 1]) ++j;
+        const int c = gc - jobs.col_begin[j];
+        const int N = jobs.cols[j], R = jobs.rows[j];
+        const float* p = jobs.parts[j] + c;
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) s += p[(int64_t)r * N];
+        jobs.out[j][c] = s;
+        sq = s * s;
+    }
+    if (sumsq != nullptr) {
+        const float bsq = block_sum(sq, red);
+        if (threadIdx.x == 0)
+            atomicAdd(sumsq + (CODAE_S_GRAD_SQ_SLOTS - CODAE_S_GRAD_SQ) + (blockIdx.x & (CODAE_S_N_SLOTS - 1)), (double)bsq);
     }
 }
 
@@ -465,7 +492,7 @@ inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) ==
 
 }  // namespace
 
-int launch_gather_corrupt(const codae_batch* b, void* out, int out_bf16, hipStream_t s, float* zero_ptr, int64_t zero_n) {
+int launch_gather_corrupt(const codae_batch* b, void* out, int out_bf16, hipStream_t s) {
     CODAE_REQUIRE(b && b->data && out && b->B > 0 && b->io > 0, "gather_corrupt: bad batch");
     const bool masked = b->mask_id || b->mask_to_use;
     CODAE_REQUIRE(!masked || b->mask_table, "gather_corrupt: mask ids without mask_table");
@@ -476,14 +503,12 @@ int launch_gather_corrupt(const codae_batch* b, void* out, int out_bf16, hipStre
     const int grid = grid_for(items);
     if (vec && out_bf16 && b->io % 8 == 0 && (!masked || (reinterpret_cast<uintptr_t>(b->mask_table) & 7) == 0)) {
         hipLaunchKernelGGL(gather_corrupt_bf16x8_kernel, dim3(grid_for(items / 2)), dim3(NT), 0, s, b->data, b->row_idx, b->mask_id,
-                           b->mask_table, b->B, b->io, reinterpret_cast<bf16_t*>(out), b->mask_to_use, b->nb_run, b->run,
-                           zero_ptr, zero_ptr ? zero_n : 0);
+                           b->mask_table, b->B, b->io, reinterpret_cast<bf16_t*>(out), b->mask_to_use, b->nb_run, b->run);
         CODAE_LAUNCH_CHECK();
         return CODAE_OK;
     }
 #define GC(V, O) hipLaunchKernelGGL((gather_corrupt_kernel<V, O>), dim3(grid), dim3(NT), 0, s, b->data, b->row_idx, \
-                                    b->mask_id, b->mask_table, b->B, b->io, out, b->mask_to_use, b->nb_run, b->run, \
-                                    zero_ptr, zero_ptr ? zero_n : 0)
+                                    b->mask_id, b->mask_table, b->B, b->io, out, b->mask_to_use, b->nb_run, b->run)
     if (vec && out_bf16) GC(true, true);
     else if (vec) GC(true, false);
     else if (out_bf16) GC(false, true);
@@ -524,7 +549,9 @@ int launch_expand_masks(const int32_t* mask_id, const uint8_t* table, const int3
     return CODAE_OK;
 }
 
-int launch_mse_loss(const codae_batch* b, const float* y, void* dy, int dy_bf16, float inv_n, float* colsum,
+int mse_loss_colsum_rows(int B) { return (B + LOSS_ROWS - 1) / LOSS_ROWS; }
+
+int launch_mse_loss(const codae_batch* b, const float* y, void* dy, int dy_bf16, float inv_n, float* colsum_part,
                     double* scalars, int want_grad, hipStream_t s) {
     CODAE_REQUIRE(b && b->data && y && scalars && b->B > 0 && b->io > 0, "mse_loss: bad args");
     CODAE_REQUIRE(!want_grad || dy, "mse_loss: gradient requested without dy");
@@ -534,7 +561,7 @@ int launch_mse_loss(const codae_batch* b, const float* y, void* dy, int dy_bf16,
                      (!masked || (reinterpret_cast<uintptr_t>(b->mask_table) & 3) == 0);
     const int grid = (b->B + LOSS_ROWS - 1) / LOSS_ROWS;
 #define ML(V, O) hipLaunchKernelGGL((mse_loss_kernel<V, O>), dim3(grid), dim3(NT), 0, s, b->data, b->row_idx, \
-                                    b->mask_id, b->mask_table, b->B, b->io, y, dy, inv_n, colsum, scalars, want_grad, \
+                                    b->mask_id, b->mask_table, b->B, b->io, y, dy, inv_n, colsum_part, scalars, want_grad, \
                                     b->mask_to_use, b->nb_run, b->run)
     if (vec && dy_bf16) ML(true, true);
     else if (vec) ML(true, false);
@@ -725,7 +752,23 @@ int launch_clip_adam_tiled(float* p, float* g, float* m, float* v, const codae_h
 
 int launch_colsum_f32(const float* src, int M, int N, float* out, hipStream_t s) {
     CODAE_REQUIRE(src && out && M > 0 && N > 0, "colsum: bad args");
-    hipLaunchKernelGGL(colsum_f32_kernel, dim3((M + 63) / 64), dim3(NT), 0, s, src, M, N, out);
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3((N + NT - 1) / NT), dim3(NT), 0, s, src, M, N, out);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+int launch_colsum_parts_f32(const float* src, int M, int N, float* parts, hipStream_t s) {
+    CODAE_REQUIRE(src && parts && M > 0 && N > 0, "colsum_parts: bad args");
+    hipLaunchKernelGGL(colsum_parts_f32_kernel, dim3((M + 63) / 64), dim3(NT), 0, s, src, M, N, parts);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+int launch_bias_finish(const BiasFinishJobs& jobs, double* sumsq, hipStream_t s) {
+    CODAE_REQUIRE(jobs.n > 0 && jobs.n <= 64, "bias_finish: %d jobs", jobs.n);
+    const int total = jobs.col_begin[jobs.n];
+    CODAE_REQUIRE(total > 0, "bias_finish: no columns");
+    hipLaunchKernelGGL(bias_finish_kernel, dim3((total + NT - 1) / NT), dim3(NT), 0, s, jobs, sumsq);
     CODAE_LAUNCH_CHECK();
     return CODAE_OK;
 }
@@ -749,10 +792,9 @@ int launch_transpose_bf16(const bf16_t* src, bf16_t* dst, int n, const int64_t* 
 }
 
 int launch_reduce_slabs(const float* slabs, int n_slabs, int64_t stride, float* out, int64_t n, double* sumsq,
-                        hipStream_t s, const float* extra, int n_extra) {
+                        hipStream_t s) {
     CODAE_REQUIRE(slabs && out && n_slabs >= 1 && n > 0, "reduce_slabs: bad args");
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, s, slabs, n_slabs, stride, out, n, sumsq,
-                       (sumsq && extra) ? extra : nullptr, (sumsq && extra) ? n_extra : 0);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, s, slabs, n_slabs, stride, out, n, sumsq);
     CODAE_LAUNCH_CHECK();
     return CODAE_OK;
 }

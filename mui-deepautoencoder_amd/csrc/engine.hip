@@ -71,6 +71,11 @@ struct codae_engine {
     int64_t act_bytes = 0, dact_one = 0, slab_bytes = 0;
     int n_dact = 3;          // rotating activation-gradient buffers: min(L + 1, CODAE_MAX_DACT)
     std::vector<int> split_k;
+    // bias gradients: per layer a block of partial column-sum rows in bufs->bias_parts, filled by whichever kernel
+    // produces that layer's activation gradient; parts_pending[l] = rows waiting for finish_bias (0 = none)
+    std::vector<int64_t> part_off;
+    int64_t part_floats = 0;
+    mutable std::vector<int> parts_pending;
     // optional per-launch hipEvent pairs (codae_profile_begin / _end)
     // backward on two streams: the weight-gradient GEMMs (+ slab reduce) run on `side`, concurrently with
     // the data-gradient chain on the caller's stream (they only share the read-only dA_l)
@@ -173,6 +178,7 @@ int choose_split_k(int N, int K, int rows) {
 inline void* act_ptr(const codae_engine* e, const codae_buffers* b, int l) {
     return reinterpret_cast<char*>(b->acts) + e->act_off[l];
 }
+inline float* part_ptr(const codae_engine* e, const codae_buffers* b, int l) { return b->bias_parts + e->part_off[l]; }
 inline void* dact_ptr(const codae_engine* e, const codae_buffers* b, int l) {
     return reinterpret_cast<char*>(b->dacts) + (int64_t)(l % e->n_dact) * e->dact_one;   // see backward_range
 }
@@ -183,6 +189,34 @@ int check_common(codae_handle h, const codae_buffers* b, int B) {
     CODAE_REQUIRE(b->params && b->acts, "params/acts buffer missing");
     CODAE_REQUIRE(h->prec != CODAE_PREC_BF16 || b->shadow_w, "bf16 mode needs shadow_w");
     return CODAE_OK;
+}
+
+// db_l = sum of layer l's pending partial column-sum rows, in row order (every layer with pending rows, one launch);
+// with_norm: += sum db^2 into the clip_grad_norm_ slots
+int finish_bias(const codae_engine* e, const codae_buffers* b, hipStream_t s, bool with_norm) {
+    BiasFinishJobs jobs;
+    jobs.n = 0;
+    int cols = 0;
+    for (int l = 0; l < e->L; ++l) {
+        if (e->parts_pending[l] <= 0) continue;
+        if (jobs.n == 64) {                                   // (more than 64 layers pending: several launches)
+            jobs.col_begin[jobs.n] = cols;
+            int rc = launch_bias_finish(jobs, with_norm ? b->scalars + CODAE_S_GRAD_SQ : nullptr, s);
+            if (rc) return rc;
+            jobs.n = 0; cols = 0;
+        }
+        jobs.parts[jobs.n] = part_ptr(e, b, l);
+        jobs.out[jobs.n] = b->grads + e->b_off[l];
+        jobs.rows[jobs.n] = e->parts_pending[l];
+        jobs.cols[jobs.n] = e->out[l];
+        jobs.col_begin[jobs.n] = cols;
+        cols += e->out[l];
+        ++jobs.n;
+        e->parts_pending[l] = 0;
+    }
+    if (jobs.n == 0) return CODAE_OK;
+    jobs.col_begin[jobs.n] = cols;
+    return launch_bias_finish(jobs, with_norm ? b->scalars + CODAE_S_GRAD_SQ : nullptr, s);
 }
 
 // y = act(x W^T + b) for layer l
@@ -232,8 +266,7 @@ int run_wgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, hi
             if (rc) return rc;
             ProfScope prof(e, CODAE_K_SLAB_REDUCE, s);
             return launch_reduce_slabs(reinterpret_cast<const float*>(slab), S, (int64_t)N * K, dW, (int64_t)N * K,
-                                       e->norm_in_backward ? b->scalars + CODAE_S_GRAD_SQ : nullptr, s,
-                                       b->grads + e->b_off[l], N);
+                                       e->norm_in_backward ? b->scalars + CODAE_S_GRAD_SQ : nullptr, s);
         }
         g.C = dW;
         ProfScope prof(e, CODAE_K_GEMM_WGRAD, s);
@@ -269,7 +302,8 @@ int run_dgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, fl
         } else {
             g.C = dact_ptr(e, b, l - 1); g.c_f32 = 0;
             if (e->relu[l - 1]) { g.relu_src = reinterpret_cast<const bf16_t*>(act_ptr(e, b, l)); g.ld_relu = K; }
-            g.colsum = b->grads + e->b_off[l - 1];
+            g.colsum_part = part_ptr(e, b, l - 1);
+            e->parts_pending[l - 1] = gemm_bf16_colsum_rows(g);
         }
         return gemm_bf16(g, s);
     }
@@ -283,7 +317,8 @@ int run_dgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, fl
     } else {
         g.C = reinterpret_cast<float*>(dact_ptr(e, b, l - 1));
         if (e->relu[l - 1]) { g.relu_src = reinterpret_cast<const float*>(act_ptr(e, b, l)); g.ld_relu = K; }
-        g.colsum = b->grads + e->b_off[l - 1];
+        g.colsum_part = part_ptr(e, b, l - 1);
+        e->parts_pending[l - 1] = gemm_f32_colsum_rows(rows);
     }
     return gemm_f32(g, s);
 }
@@ -392,6 +427,12 @@ int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi
             if (rc) return rc;
         }
     }
+    // bias gradients of every layer whose activation gradient was produced since the last call (this range's dgrads;
+    // the loss, when the range starts at the top): partial rows -> grads' bias block, on the caller's stream
+    {
+        int rc = finish_bias(h, b, s, h->norm_in_backward);
+        if (rc) return rc;
+    }
     if (dual) {
         h->side_dirty = true;
         if (join) return join_side(h, s);
@@ -477,6 +518,15 @@ int codae_create(const codae_spec* spec, codae_handle* out) {
     // two backward streams, whose barrier packets cost ~11 us each); deeper stacks rotate through CODAE_MAX_DACT
     e->n_dact = e->L + 1 <= CODAE_MAX_DACT ? e->L + 1 : CODAE_MAX_DACT;
     if (e->n_dact < 3) e->n_dact = 3;
+    // partial column-sum rows per layer: a producer writes at most one row per 64 batch rows (exact-fp32 GEMM, dense
+    // colsum), the stand-alone loss kernel of the last layer one per 32
+    e->parts_pending.assign(e->L, 0);
+    e->part_floats = 0;
+    for (int l = 0; l < e->L; ++l) {
+        e->part_off.push_back(e->part_floats);
+        const int64_t rows_cap = (l == e->L - 1) ? (e->max_rows + 31) / 32 : (e->max_rows + 63) / 64;
+        e->part_floats += round_up(rows_cap * (int64_t)e->out[l], 64);
+    }
     e->slab_bytes = 0;
     for (int l = 0; l < e->L; ++l) {
         int s = 1;
@@ -553,6 +603,7 @@ int codae_get_sizes(codae_handle h, codae_sizes* out) {
     out->act_bytes = h->act_bytes;
     out->dact_bytes = h->n_dact * h->dact_one;
     out->slab_bytes = 3 * h->slab_bytes;   // side stream: two alternating slab buffers; caller's stream (tail wgrad): the third
+    out->bias_part_bytes = h->part_floats * 4;
     out->n_scalars = CODAE_S_COUNT;
     return CODAE_OK;
 }
@@ -612,18 +663,17 @@ int codae_backward(codae_handle h, const codae_buffers* b, const float* dy, floa
     hipStream_t s = (hipStream_t)stream;
     const int rows = h->rows_for(B);
     const int top = layer_hi - 1;
-    // bias gradients are accumulated with atomics by the producers of dA_l: clear this range
-    for (int l = layer_lo; l < layer_hi; ++l)
-        CODAE_HIP_CHECK(hipMemsetAsync(b->grads + h->b_off[l], 0, (size_t)round_up(h->out[l], 64) * sizeof(float), s));
-    // dA_top = dy in working precision; db_top = column sums of dy
+    CODAE_REQUIRE(b->bias_parts, "codae_backward: bias_parts missing");
+    // dA_top = dy in working precision; db_top = column sums of dy (per 64-row block here, added up after the chain)
     codae_batch in{};
     in.data = dy; in.B = B; in.io = h->out[top];
     rc = launch_gather_corrupt(&in, dact_ptr(h, b, top), h->prec == CODAE_PREC_BF16, s);
     if (rc) return rc;
     rc = zero_pad_rows(h, dact_ptr(h, b, top), B, rows, h->out[top], s);
     if (rc) return rc;
-    rc = launch_colsum_f32(dy, B, h->out[top], b->grads + h->b_off[top], s);
+    rc = launch_colsum_parts_f32(dy, B, h->out[top], part_ptr(h, b, top), s);
     if (rc) return rc;
+    h->parts_pending[top] = (B + 63) / 64;
     return backward_range(h, b, B, layer_lo, layer_hi, dx, false, s);
 }
 
@@ -635,6 +685,7 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
     CODAE_REQUIRE(batch->io == h->in[0] && batch->io == h->out[h->L - 1], "batch.io %d does not match the model (%d -> %d)",
                   batch->io, h->in[0], h->out[h->L - 1]);
     CODAE_REQUIRE(b->grads && b->dacts && b->scalars, "codae_step_forward_loss: grads / dacts / scalars missing");
+    CODAE_REQUIRE(hyper == nullptr || b->bias_parts, "codae_step_forward_loss: bias_parts missing");
     if (h->prof_on) ++h->prof_step;
     hipStream_t s = (hipStream_t)stream;
     const int B = batch->B, L = h->L;
@@ -642,9 +693,7 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
     const bool bf = h->prec == CODAE_PREC_BF16;
     {
         ProfScope prof(h, CODAE_K_GATHER, s);
-        // training step: the bias-gradient block (accumulated with atomics from the loss on) is cleared here
-        rc = launch_gather_corrupt(batch, act_ptr(h, b, 0), bf, s, hyper != nullptr ? b->grads + h->bias_begin : nullptr,
-                                   h->n_param - h->bias_begin);
+        rc = launch_gather_corrupt(batch, act_ptr(h, b, 0), bf, s);
     }
     if (rc) return rc;
     rc = zero_pad_rows(h, act_ptr(h, b, 0), B, rows, h->in[0], s);
@@ -664,7 +713,7 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
             g.C = dact_ptr(h, b, l); g.ldc = h->out[l]; g.c_f32 = 0;
             g.M = rows; g.N = h->out[l]; g.K = h->in[l];
             g.bias = b->params + h->b_off[l]; g.relu = 0; g.split_k = 1;
-            g.colsum = b->grads + h->b_off[l];
+            g.colsum_part = part_ptr(h, b, l);
             g.loss.enabled = 1; g.loss.data = batch->data; g.loss.row_idx = batch->row_idx; g.loss.mask_id = batch->mask_id;
             g.loss.mask_to_use = batch->mask_to_use; g.loss.nb_run = batch->nb_run; g.loss.run = batch->run;
             g.loss.table = batch->mask_table; g.loss.io = batch->io; g.loss.B = B; g.loss.inv_n = (float)(1.0 / n_glob);
@@ -674,6 +723,7 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
                 rc = gemm_bf16(g, s);
             }
             if (rc) return rc;
+            h->parts_pending[l] = gemm_bf16_colsum_rows(g);
             h->norm_scalars_zero = true;
             return launch_finish_loss(b->scalars, 1.0 / ((double)B * batch->io), s);
         }
@@ -689,10 +739,11 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
         if (rc) return rc;
         {
             ProfScope prof(h, CODAE_K_LOSS, s);
-            rc = launch_mse_loss(batch, y, dact_ptr(h, b, L - 1), bf, (float)(1.0 / n_glob), b->grads + h->b_off[L - 1],
+            rc = launch_mse_loss(batch, y, dact_ptr(h, b, L - 1), bf, (float)(1.0 / n_glob), part_ptr(h, b, L - 1),
                                  b->scalars, 1, s);
         }
         if (rc) return rc;
+        h->parts_pending[L - 1] = mse_loss_colsum_rows(B);
         h->norm_scalars_zero = true;
         return launch_finish_loss(b->scalars, 1.0 / ((double)B * batch->io), s);
     }
@@ -911,10 +962,7 @@ int codae_wgrad_f32(const float* dy, const float* x, float* dW, float* db, int32
     g.C = dW; g.ldc = K; g.M = N; g.N = K; g.K = M;
     int rc = gemm_f32(g, (hipStream_t)stream);
     if (rc) return rc;
-    if (db) {
-        CODAE_HIP_CHECK(hipMemsetAsync(db, 0, (size_t)N * sizeof(float), (hipStream_t)stream));
-        return launch_colsum_f32(dy, M, N, db, (hipStream_t)stream);
-    }
+    if (db) return launch_colsum_f32(dy, M, N, db, (hipStream_t)stream);
     return CODAE_OK;
 }
 
@@ -929,16 +977,22 @@ int codae_linear_bf16(const void* x, const void* W, const float* bias, void* y, 
     return gemm_bf16(g, (hipStream_t)stream);
 }
 
-int codae_dgrad_bf16(const void* dy, const void* W, const void* relu_src, void* dx, float* db_prev, int32_t M, int32_t N,
-                     int32_t K, void* stream) {
+int codae_dgrad_bf16(const void* dy, const void* W, const void* relu_src, void* dx, float* db_prev, float* db_ws, int32_t M,
+                     int32_t N, int32_t K, void* stream) {
     CODAE_REQUIRE(dy && W && dx, "codae_dgrad_bf16: null operand");
+    CODAE_REQUIRE(db_prev == nullptr || db_ws != nullptr, "codae_dgrad_bf16: db_prev needs the db_ws scratch");
     GemmBf16 g{};
     g.A = reinterpret_cast<const bf16_t*>(dy); g.lda = N; g.a_mode = OP_KC;
     g.B = reinterpret_cast<const bf16_t*>(W); g.ldb = K; g.b_mode = OP_KS;
     g.C = dx; g.ldc = K; g.c_f32 = 0; g.M = M; g.N = K; g.K = N;
     g.relu_src = reinterpret_cast<const bf16_t*>(relu_src); g.ld_relu = K;
-    g.colsum = db_prev; g.split_k = 1;
-    return gemm_bf16(g, (hipStream_t)stream);
+    g.colsum_part = db_prev ? db_ws : nullptr; g.split_k = 1;
+    int rc = gemm_bf16(g, (hipStream_t)stream);
+    if (rc || db_prev == nullptr) return rc;
+    BiasFinishJobs jobs;
+    jobs.n = 1; jobs.parts[0] = db_ws; jobs.out[0] = db_prev; jobs.rows[0] = gemm_bf16_colsum_rows(g); jobs.cols[0] = K;
+    jobs.col_begin[0] = 0; jobs.col_begin[1] = K;
+    return launch_bias_finish(jobs, nullptr, (hipStream_t)stream);
 }
 
 int codae_wgrad_bf16(const void* dy, const void* x, float* dW, void* slabs, int64_t slab_bytes, int32_t M, int32_t N,

@@ -266,34 +266,34 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
         if (nkt == 0) __syncthreads();                          // (rowinfo otherwise published by the K loop's barriers)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-            // all of this pass's x rows and mask bytes are requested before the tile half is staged:
-            // one exposed gather latency per pass instead of one per row
+            // all of this pass's x rows and mask bytes are requested before the tile half is staged: one exposed gather
+            // latency per pass instead of one per row.  The loads are UNCONDITIONAL, from clamped (always valid) addresses,
+            // and dead lanes are masked out of the arithmetic instead: a branch around each load makes the compiler wait
+            // for every load before issuing the next (round 1 had them conditional: the epilogue ran ~14 dependent HBM
+            // round trips, 30 us instead of ~12).
             float4 xa[ITER], xb[ITER];
             uint2 mk[ITER];
             bool live[ITER];
+            const int jc = j < g.N ? j : 0;
+            const uint8_t* tb = masked ? L.table : reinterpret_cast<const uint8_t*>(L.data);   // (unmasked: any valid bytes)
 #pragma unroll
             for (int it = 0; it < ITER; ++it) {
                 const int r = rl + it * RL;
-                live[it] = false;
-                xa[it] = make_float4(0.f, 0.f, 0.f, 0.f); xb[it] = xa[it];
-                mk[it] = make_uint2(0x01010101u, 0x01010101u);
-                if (rl < RL && j < g.N && r < HR) {
-                    const int src_row = rowinfo[2 * (hh * HR + r)];
-                    if (src_row >= 0) {
-                        live[it] = true;
-                        const float* xp = L.data + (int64_t)src_row * L.io + j;
-                        xa[it] = *reinterpret_cast<const float4*>(xp);
-                        xb[it] = *reinterpret_cast<const float4*>(xp + 4);
-                        if (masked) mk[it] = *reinterpret_cast<const uint2*>(L.table + (int64_t)rowinfo[2 * (hh * HR + r) + 1] * L.io + j);
-                    }
-                }
+                const int rr = (rl < RL && r < HR) ? r : 0;
+                const int src_row = rowinfo[2 * (hh * HR + rr)];
+                const int id = rowinfo[2 * (hh * HR + rr) + 1];
+                live[it] = rl < RL && j < g.N && r < HR && src_row >= 0;
+                const float* xp = L.data + (int64_t)(src_row >= 0 ? src_row : 0) * L.io + jc;
+                xa[it] = *reinterpret_cast<const float4*>(xp);
+                xb[it] = *reinterpret_cast<const float4*>(xp + 4);
+                const uint2 mv = *reinterpret_cast<const uint2*>(tb + (int64_t)id * L.io + jc);
+                mk[it] = masked ? mv : make_uint2(0x01010101u, 0x01010101u);
             }
             if (((BM / WM) * wr) / HR == hh) {
 #pragma unroll
                 for (int nt = 0; nt < TN; ++nt) {
                     const int jl = (BN / WN) * wc + 16 * nt + g4;
-                    float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (g.bias != nullptr && j0 + jl < g.N) bj = *reinterpret_cast<const float4*>(g.bias + j0 + jl);
+                    const float4 bj = load_bias4(g.bias, g.A, j0 + jl, g.N);
 #pragma unroll
                     for (int mt = 0; mt < TM; ++mt) {
                         const int il = (BM / WM) * wr + 16 * mt + li - hh * HR;
@@ -356,11 +356,11 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
             atomicAdd(&L.scalars[CODAE_S_STEP_SQ], (double)a);
             if (masked) atomicAdd(&L.scalars[CODAE_S_SQ_PARTIAL], (double)b2);
         }
-        if (g.colsum != nullptr) {
+        if (g.colsum_part != nullptr) {
             for (int col = threadIdx.x; col < BN; col += NT) {
                 float sum = 0.f;
                 for (int r = 0; r < RL; ++r) sum += red[r * BN + col];
-                if (j0 + col < g.N) atomicAdd(&g.colsum[j0 + col], sum);
+                if (j0 + col < g.N) g.colsum_part[(int64_t)tm * g.N + j0 + col] = sum;
             }
         }
         return;
@@ -379,8 +379,7 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
         for (int nt = 0; nt < TN; ++nt) {
             const int jl = (BN / WN) * wc + 16 * nt + g4;
             const int j = j0 + jl;
-            float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g.bias != nullptr && j < g.N) bj = *reinterpret_cast<const float4*>(g.bias + j);
+            const float4 bj = load_bias4(g.bias, g.A, j, g.N);
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
                 const int il = (BM / WM) * wr + 16 * mt + li;
@@ -416,7 +415,7 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
                     v.x = keep(v.x, h.x); v.y = keep(v.y, h.y); v.z = keep(v.z, h.z); v.w = keep(v.w, h.w);
                 }
                 *reinterpret_cast<uint4*>(Cb + (int64_t)i * g.ldc + j) = v;
-                if (g.colsum != nullptr) {
+                if (g.colsum_part != nullptr) {
                     cs[0] += bf16_to_f32((bf16_t)(v.x & 0xffff)); cs[1] += bf16_to_f32((bf16_t)(v.x >> 16));
                     cs[2] += bf16_to_f32((bf16_t)(v.y & 0xffff)); cs[3] += bf16_to_f32((bf16_t)(v.y >> 16));
                     cs[4] += bf16_to_f32((bf16_t)(v.z & 0xffff)); cs[5] += bf16_to_f32((bf16_t)(v.z >> 16));
@@ -424,8 +423,9 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
                 }
             }
         }
-        if (g.colsum != nullptr) {
-            // column sums of the stored tile: [RL][BN] partials through LDS, then one atomic per column
+        if (g.colsum_part != nullptr) {
+            // column sums of the stored tile: [RL][BN] partials through LDS, then one plain store per column into this
+            // tile row's partial-sum row (added up in a fixed order by the bias-finish kernel: no float atomics)
             __syncthreads();
             float* red = reinterpret_cast<float*>(smem_raw);
             static_assert(RL * BN * 4 <= 2 * BUF_BYTES, "reduction scratch must fit");
@@ -437,7 +437,7 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
             for (int col = threadIdx.x; col < BN; col += NT) {
                 float sum = 0.f;
                 for (int r = 0; r < RL; ++r) sum += red[r * BN + col];
-                if (j0 + col < g.N) atomicAdd(&g.colsum[j0 + col], sum);
+                if (j0 + col < g.N) g.colsum_part[(int64_t)tm * g.N + j0 + col] = sum;
             }
         }
         return;
@@ -461,8 +461,7 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
 #pragma unroll
                 for (int nt = 0; nt < TN; ++nt) {
                     const int jl = (BN / WN) * wc + 16 * nt + g4;
-                    float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (g.bias != nullptr && j0 + jl < g.N) bj = *reinterpret_cast<const float4*>(g.bias + j0 + jl);
+                    const float4 bj = load_bias4(g.bias, g.A, j0 + jl, g.N);
 #pragma unroll
                     for (int mt = 0; mt < TM; ++mt) {
                         const int il = (BM / WM) * wr + 16 * mt + li - hh * HR;
@@ -539,6 +538,13 @@ int gemm_bf16_tile_big(int M, int N, int split_k, bool k_strided = false) {
     return 3;
 }
 
+// rows of g.colsum_part the launch gemm_bf16(g) makes will write: one per tile along M of the tile it picks
+int gemm_bf16_colsum_rows(const GemmBf16& g) {
+    const int t = gemm_bf16_tile_big(g.M, g.N, g.loss.enabled ? 1 : g.split_k, g.b_mode == OP_KS || g.c_f32);
+    const int bm = g.loss.enabled ? (t ? 256 : 128) : ((t == 1 || t == 2 || t == 3 || t == 5) ? 256 : 128);
+    return (g.M + bm - 1) / bm;
+}
+
 int gemm_bf16(const GemmBf16& g, hipStream_t s) {
     CODAE_REQUIRE(gemm_bf16_supported(g.M, g.N, g.K), "gemm_bf16: unsupported shape M=%d N=%d K=%d (need K %% 64 == 0, N %% 8 == 0)",
                   g.M, g.N, g.K);
@@ -550,7 +556,7 @@ int gemm_bf16(const GemmBf16& g, hipStream_t s) {
                       (reinterpret_cast<uintptr_t>(g.C) & 15) == 0,
                   "gemm_bf16: operands must be 16-byte aligned");
     CODAE_REQUIRE(g.split_k <= g.K / BK, "gemm_bf16: split_k %d > k tiles %d", g.split_k, g.K / BK);
-    CODAE_REQUIRE(!g.c_f32 || (g.relu_src == nullptr && g.colsum == nullptr), "gemm_bf16: ReLU mask / column sums need bf16 output");
+    CODAE_REQUIRE(!g.c_f32 || (g.relu_src == nullptr && g.colsum_part == nullptr), "gemm_bf16: ReLU mask / column sums need bf16 output");
     if (g.loss.enabled) {
         CODAE_REQUIRE(g.a_mode == OP_KC && g.b_mode == OP_KC && !g.c_f32 && g.split_k == 1 && !g.relu && !g.relu_src,
                       "gemm_bf16: fused loss only on the plain forward form");

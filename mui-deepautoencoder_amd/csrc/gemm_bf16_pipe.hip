@@ -414,8 +414,7 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
 #pragma unroll
             for (int nt = 0; nt < TNH; ++nt) {
                 const int jl = nh * BHR + wc * (SN / 2) + 16 * nt + g4;
-                float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (g.bias != nullptr && j0 + jl < g.N) bj = *reinterpret_cast<const float4*>(g.bias + j0 + jl);
+                const float4 bj = load_bias4(g.bias, g.A, j0 + jl, g.N);
 #pragma unroll
                 for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -452,7 +451,7 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
                     v.x = keep(v.x, h.x); v.y = keep(v.y, h.y); v.z = keep(v.z, h.z); v.w = keep(v.w, h.w);
                 }
                 *reinterpret_cast<uint4*>(Cb + (int64_t)i * g.ldc + j) = v;
-                if (EPI != 1 && g.colsum != nullptr) {
+                if (EPI != 1 && g.colsum_part != nullptr) {
                     cs[0] += bf16_to_f32((bf16_t)(v.x & 0xffff)); cs[1] += bf16_to_f32((bf16_t)(v.x >> 16));
                     cs[2] += bf16_to_f32((bf16_t)(v.y & 0xffff)); cs[3] += bf16_to_f32((bf16_t)(v.y >> 16));
                     cs[4] += bf16_to_f32((bf16_t)(v.z & 0xffff)); cs[5] += bf16_to_f32((bf16_t)(v.z >> 16));
@@ -462,7 +461,7 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
         }
         stamp(3);
         if constexpr (dbg_time) { wait_vmcnt<0>(); stamp(4); }
-        if (EPI != 1 && g.colsum != nullptr) {
+        if (EPI != 1 && g.colsum_part != nullptr) {
             __syncthreads();
             float* red = reinterpret_cast<float*>(smem_raw);
             static_assert(RL * BN * 4 <= 2 * BUF, "reduction scratch must fit");
@@ -474,7 +473,7 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
             for (int col = threadIdx.x; col < BN; col += NT) {
                 float sum = 0.f;
                 for (int r = 0; r < RL; ++r) sum += red[r * BN + col];
-                if (j0 + col < g.N) atomicAdd(&g.colsum[j0 + col], sum);
+                if (j0 + col < g.N) g.colsum_part[(int64_t)tm * g.N + j0 + col] = sum;
             }
         }
         return;
@@ -501,8 +500,7 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
 #pragma unroll
                 for (int nt = 0; nt < TNH; ++nt) {
                     const int jl = nh * BHR + wc * (SN / 2) + 16 * nt + g4;
-                    float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (g.bias != nullptr && j0 + jl < g.N) bj = *reinterpret_cast<const float4*>(g.bias + j0 + jl);
+                    const float4 bj = load_bias4(g.bias, g.A, j0 + jl, g.N);
 #pragma unroll
                     for (int mt = 0; mt < TMH; ++mt) {
                         const int il = wr * (SM / 2) + 16 * mt + li;          // row inside this half
@@ -537,7 +535,7 @@ int launch_pipe(const GemmBf16& g, hipStream_t s) {
 #define LAUNCH(AM, BMODE, CF, EP) \
     hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, WM, WN, NLB, AM, BMODE, CF, 0, EP>), grid, block, 0, s, g, tiles_n, tiles_m * tiles_n, kt_total)
 #define LAUNCH_BF16(AM, BMODE) do { if (bwd_epi) LAUNCH(AM, BMODE, false, 2); else LAUNCH(AM, BMODE, false, 1); } while (0)
-    const bool bwd_epi = g.relu_src != nullptr || g.colsum != nullptr;
+    const bool bwd_epi = g.relu_src != nullptr || g.colsum_part != nullptr;
     if (g.a_mode == OP_KC && g.b_mode == OP_KC) { if (g.c_f32) LAUNCH(OP_KC, OP_KC, true, 0); else LAUNCH_BF16(OP_KC, OP_KC); }
     else if (g.a_mode == OP_KC && g.b_mode == OP_KS) { if (g.c_f32) LAUNCH(OP_KC, OP_KS, true, 0); else LAUNCH_BF16(OP_KC, OP_KS); }
     else if (g.a_mode == OP_KS && g.b_mode == OP_KS) { if (g.c_f32) LAUNCH(OP_KS, OP_KS, true, 0); else LAUNCH_BF16(OP_KS, OP_KS); }

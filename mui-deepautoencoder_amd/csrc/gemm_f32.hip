@@ -146,9 +146,11 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmF32 g, bool a_vec, boo
                 }
             }
         }
-        if (g.colsum != nullptr) {
+        if (g.colsum_part != nullptr) {
+            // one partial row per 64-row wave block: no atomics, the finish kernel adds the rows in order
             csum += __shfl_xor(csum, 32);
-            if (kh == 0 && j < g.N) atomicAdd(&g.colsum[j], csum);
+            // (a wave whose 64-row block lies wholly past M has no partial row: gemm_f32_colsum_rows = ceil(M / 64))
+            if (kh == 0 && j < g.N && i0 + 64 * wr < g.M) g.colsum_part[(int64_t)(2 * blockIdx.y + wr) * g.N + j] = csum;
         }
     }
 }

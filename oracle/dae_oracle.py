@@ -23,6 +23,13 @@ those runs through this module and compares.
 Summation order: all reductions are numpy fp32 (pairwise) unless a function
 says float64; matmul is numpy's (BLAS sgemm).  Parity is therefore to
 tolerance (rtol 1e-3 / atol 1e-5, BASELINE.json north_star), not bitwise.
+
+`quant`: forward / backward / EmbeddingTrainer take an optional rounding hook.  With quant=None (the default, and
+what every golden replay uses) they are the reference's fp32 math.  With quant=bf16_round they restate WHERE the
+bf16 (throughput) engine rounds - corrupted input, weight shadow, every stored activation and activation gradient
+to bf16, every accumulation in fp32, master weights and Adam in fp32 - so the HIP kernels can be pinned tightly to
+"the reference's algorithm evaluated in that arithmetic", separately from how far that arithmetic itself sits from
+the fp32 reference run (tests/test_gpu_parity.py).
 """
 
 import itertools
@@ -174,15 +181,28 @@ def corrupt(x, mask):
     return (x * mask).astype(F32)
 
 
-def forward(params, relu_flags, x, keep=False):
-    """y = Linear/ReLU chain (embedding_...py:137-185): h = relu?(h W^T + b)."""
+def bf16_round(a):
+    """fp32 -> bf16 (round to nearest even) -> fp32: the value a bf16 store keeps."""
+    u = np.ascontiguousarray(a, dtype=F32).view(np.uint32)
+    r = (u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)
+    return r.view(F32)
+
+
+def forward(params, relu_flags, x, keep=False, quant=None):
+    """y = Linear/ReLU chain (embedding_...py:137-185): h = relu?(h W^T + b).
+    quant: operands (input, weights, every hidden activation) pass through it; the last layer's y stays fp32."""
     h = x.astype(F32)
+    if quant is not None:
+        h = quant(h)
     acts = [h]
-    for (w, b), relu in zip(params, relu_flags):
-        h = h @ w.T + b
+    last = len(params) - 1
+    for l, ((w, b), relu) in enumerate(zip(params, relu_flags)):
+        h = h @ (w if quant is None else quant(w)).T + b
         if relu:
             h = np.maximum(h, 0)
         h = h.astype(F32)
+        if quant is not None and l != last:
+            h = quant(h)
         acts.append(h)
     return (h, acts) if keep else h
 
@@ -311,21 +331,28 @@ def normalizer_undo(data, scale, dmin):
 # a6: backward of the Linear/ReLU chain
 # --------------------------------------------------------------------------
 
-def backward(params, relu_flags, acts, dy):
+def backward(params, relu_flags, acts, dy, quant=None):
     """Gradients [(dW, db)] of the chain (autograd of embedding_...py:137-185).
 
     acts[l] is the input of layer l, acts[l+1] its (post-ReLU) output.
     dA = dH * [h>0] uses the post-activation (ReLU(inplace=True), :64).
+    quant: every activation gradient is stored through it (the last layer's bias gradient sums the unrounded dy).
     """
     grads = [None] * len(params)
     d = dy.astype(F32)
+    db_top = d.sum(axis=0, dtype=F32)
+    if quant is not None:
+        d = quant(d)
     for l in range(len(params) - 1, -1, -1):
         w, _ = params[l]
         if relu_flags[l]:
             d = (d * (acts[l + 1] > 0)).astype(F32)
-        grads[l] = ((d.T @ acts[l]).astype(F32), d.sum(axis=0, dtype=F32))
+        db = db_top if (quant is not None and l == len(params) - 1) else d.sum(axis=0, dtype=F32)
+        grads[l] = ((d.T @ acts[l]).astype(F32), db)
         if l > 0:
-            d = (d @ w).astype(F32)
+            d = (d @ (w if quant is None else quant(w))).astype(F32)
+            if quant is not None:
+                d = quant(d)
     return grads
 
 
@@ -464,18 +491,21 @@ def ranking_loss(prediction, fmask, indices, data_per_category, embedding_size,
 class EmbeddingTrainer:
     """State + one step of the inner loop of script/train_dae_on_embedding.py:194-223."""
 
-    def __init__(self, params, relu_flags, lr, weight_decay, clip=True):
+    def __init__(self, params, relu_flags, lr, weight_decay, clip=True, quant=None):
         self.params = [(w.astype(F32).copy(), b.astype(F32).copy()) for w, b in params]
         self.relu = list(relu_flags)
         self.lr, self.wd, self.clip = lr, weight_decay, clip
         self.adam = adam_init(self.params)
+        self.quant = quant
+        self.last_grads = None
 
     def step(self, x, fmask):
         """Returns dict(loss, grad_norm, sq_full, sq_partial, y)."""
         c = corrupt(x, fmask)                                     # :200
-        y, acts = forward(self.params, self.relu, c, keep=True)   # :203
+        y, acts = forward(self.params, self.relu, c, keep=True, quant=self.quant)   # :203
         loss = mse_mean(x, y)                                     # :206
-        grads = backward(self.params, self.relu, acts, mse_mean_grad_y(x, y))  # :210
+        grads = backward(self.params, self.relu, acts, mse_mean_grad_y(x, y), quant=self.quant)  # :210
+        self.last_grads = grads
         gnorm = None
         if self.clip:
             grads, gnorm = clip_grad_norm(grads, 1.0)             # :213
@@ -487,7 +517,7 @@ class EmbeddingTrainer:
 
     def evaluate(self, x, fmask):
         """Validation body (:245-258), no parameter update."""
-        y = forward(self.params, self.relu, corrupt(x, fmask))
+        y = forward(self.params, self.relu, corrupt(x, fmask), quant=self.quant)
         se = ((x - y) ** 2).astype(F32)
         return {"y": y, "sq_full": F32(np.sum(se)), "sq_partial": F32(np.sum((1 - fmask) * se))}
 

@@ -153,8 +153,10 @@ def test_dgrad_bf16_exact_integers(hip, tile, M, N, K):
     dy, W, h = ints((M, N), g, -2, 3), ints((N, K), g, -2, 3), ints((M, K), g, -1, 2)
     dyb, Wb, hb = dy.to(dev()).bfloat16(), W.to(dev()).bfloat16(), h.to(dev()).bfloat16()
     dx = torch.full((M, K), float("nan"), device=dev(), dtype=torch.bfloat16)
-    db = torch.zeros(K, device=dev())
-    hip.check(hip.lib().codae_dgrad_bf16(hip.ptr(dyb), hip.ptr(Wb), hip.ptr(hb), hip.ptr(dx), hip.ptr(db), M, N, K, hip.current_stream()))
+    db = torch.full((K,), float("nan"), device=dev())                         # overwritten, not accumulated into
+    ws = torch.full(((M + 127) // 128 * K,), float("nan"), device=dev())     # partial column sums (scratch)
+    hip.check(hip.lib().codae_dgrad_bf16(hip.ptr(dyb), hip.ptr(Wb), hip.ptr(hb), hip.ptr(dx), hip.ptr(db), hip.ptr(ws), M, N, K,
+                                         hip.current_stream()))
     sync()
     ref = (f64(dy) @ f64(W)) * (f64(h) > 0)
     refb = f64(torch.from_numpy(ref).bfloat16())
@@ -197,7 +199,7 @@ def test_bf16_gemms_full_size_random(hip):
     assert np.allclose(f64(y[rows].float()), ref, rtol=1e-2, atol=1e-2)
     dy = (torch.randn(M, N, generator=g) * 1e-3).to(dev()).bfloat16()
     dx = torch.empty(M, K, device=dev(), dtype=torch.bfloat16)
-    hip.check(L.codae_dgrad_bf16(hip.ptr(dy), hip.ptr(W), None, hip.ptr(dx), None, M, N, K, hip.current_stream()))
+    hip.check(L.codae_dgrad_bf16(hip.ptr(dy), hip.ptr(W), None, hip.ptr(dx), None, None, M, N, K, hip.current_stream()))
     dW = torch.empty(N, K, device=dev())
     slabs = torch.empty(8 * N * K, device=dev())
     hip.check(L.codae_wgrad_bf16(hip.ptr(dy), hip.ptr(x), hip.ptr(dW), hip.ptr(slabs), slabs.numel() * 4, M, N, K, hip.current_stream()))

@@ -69,7 +69,7 @@ def _replay_fused(g, adapter):
     return replay_embedding(g, adapter)
 
 
-@pytest.mark.parametrize("name", ["embedding_square", "embedding_taper"])
+@pytest.mark.parametrize("name", ["embedding_square", "embedding_taper", "embedding_wide_square", "embedding_wide_taper"])
 def test_fused_step_replays_reference_run_f32(name):
     g = Golden(name)
     ad = FusedTrainerAdapter(g, "f32")
@@ -82,6 +82,8 @@ def test_fused_step_replays_reference_run_f32(name):
     for l, (gw, gb) in enumerate(g.params("final")):
         assert close(eng.weight(l).cpu().numpy(), gw), ("W", l)
         assert close(eng.bias(l).cpu().numpy(), gb), ("b", l)
+    if "adam_m__0" not in g.z.files:            # (the 64-multiple fixtures carry no Adam moments: file size)
+        return
     for l, ((mw, mb), (vw, vb)) in enumerate(zip(g.list("adam_m"), g.list("adam_v"))):
         assert close(eng._view(eng.adam_m, l, False).cpu().numpy(), mw, atol=1e-7)
         assert close(eng._view(eng.adam_m, l, True).cpu().numpy(), mb, atol=1e-7)
@@ -89,8 +91,119 @@ def test_fused_step_replays_reference_run_f32(name):
         assert close(eng._view(eng.adam_v, l, True).cpu().numpy(), vb, atol=1e-10)
 
 
-def test_fused_first_step_grads_f32():
-    g = Golden("embedding_square")
+# ---- the bf16 (throughput, benchmarked) engine against REFERENCE runs -------------------------------------------------
+# Stated tolerance of the bf16 mode (derived from tools/bf16_curve_dev.py on MI355X, which prints
+# the deviations of exactly these replays: every bound below is ~2x the largest deviation measured, not wider):
+# measured (r02, MI355X; wide_square / wide_taper): step loss 9.5e-4 / 3.9e-4, grad norm 1.6e-2 / 1.3e-2, book metrics
+# <= 3.8e-4 / 8.6e-5, ranking loss 1.3e-3 / 8.4e-4, weight update 3.9e-2 / 2.4e-2, first-step gradients 0.15 / 0.06
+BF16_STEP_LOSS_RTOL = 2e-3        # per-step training loss, every step of the run
+BF16_STEP_GNORM_RTOL = 3.5e-2     # per-step clip_grad_norm_ total norm
+BF16_BOOK_RTOL = 1e-3             # per-epoch ftl / ptl / fvl / pvl (RMSE-type metrics)
+BF16_RL_ATOL = 3e-3               # per-epoch ranking loss (a mean of rank fractions in [0, 1])
+BF16_UPDATE_REL_L2 = 0.08         # ||(p - p0) - (p_ref - p0)|| / ||p_ref - p0|| per weight matrix after the whole run
+# first-step gradients, per tensor, relative L2 vs the reference's fp32 gradients.  bf16 rounding of the activations
+# flips the ReLU mask of the ~0.3 % of units whose pre-activation is within rounding of zero, per layer, and the
+# flipped terms are O(1) each: the error grows towards the first layer (10 layers: 0.4 % at the output layer, 15 % at
+# layer 0).  That this is the arithmetic and not the kernels is pinned by test_fused_bf16_matches_bf16_rounded_oracle.
+BF16_GRAD0_REL_L2 = {"embedding_wide_square": 0.30, "embedding_wide_taper": 0.12}
+
+
+def _rel_l2(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def bf16_replay_deviations(name):
+    """Replay a reference run through the bf16 fused step; {quantity: largest deviation} (also used by
+    tools/bf16_curve_dev.py to derive the tolerances above)."""
+    g = Golden(name)
+    ad = FusedTrainerAdapter(g, "bf16")
+    book, steps, _ = _replay_fused(g, ad)
+    ref_l, ref_n = g["step_loss"], g["step_grad_norm"]
+    dev = {"steps": len(ref_l),
+           "step_loss": float(np.max(np.abs(np.asarray(steps["loss"]) - ref_l) / np.abs(ref_l))),
+           "step_grad_norm": float(np.max(np.abs(np.asarray(steps["grad_norm"]) - ref_n) / np.abs(ref_n)))}
+    for k in ("ftl", "ptl", "fvl", "pvl"):
+        dev["book_" + k] = float(np.max(np.abs(np.asarray(book[k], dtype=np.float64) - g["book_" + k]) / np.abs(g["book_" + k])))
+    dev["book_rl_abs"] = float(np.max(np.abs(np.asarray(book["rl"], dtype=np.float64) - g["book_rl"])))
+    eng = ad.t.engine
+    upd_w, upd_b = [], []
+    for l, ((w0, b0), (w1, b1)) in enumerate(zip(g.params("init"), g.params("final"))):
+        upd_w.append(_rel_l2(eng.weight(l).cpu().numpy() - w0, w1 - w0))
+        upd_b.append(_rel_l2(eng.bias(l).cpu().numpy() - b0, b1 - b0))
+    dev["update_w"] = max(upd_w); dev["update_b"] = max(upd_b)
+    dev["loss_first_last"] = (float(ref_l[0]), float(ref_l[-1]))
+    return dev
+
+
+@pytest.mark.parametrize("name", ["embedding_wide_square", "embedding_wide_taper"])
+def test_fused_bf16_replays_reference_run(name):
+    """The BENCHMARKED mode pinned to the reference: a whole run of the reference's own script (4 epochs, 36 optimizer
+    steps + validation, widths multiples of 64) replayed through the bf16 engine; the loss curve is asserted per step."""
+    d = bf16_replay_deviations(name)
+    assert d["steps"] == 36
+    assert d["loss_first_last"][1] < 0.9 * d["loss_first_last"][0]           # the curve moves: not a flat line compared
+    assert d["step_loss"] <= BF16_STEP_LOSS_RTOL, d
+    assert d["step_grad_norm"] <= BF16_STEP_GNORM_RTOL, d
+    for k in ("ftl", "ptl", "fvl", "pvl"):
+        assert d["book_" + k] <= BF16_BOOK_RTOL, (k, d)
+    assert d["book_rl_abs"] <= BF16_RL_ATOL, d
+    assert d["update_w"] <= BF16_UPDATE_REL_L2, d
+
+
+@pytest.mark.parametrize("name", ["embedding_wide_square", "embedding_wide_taper"])
+def test_fused_bf16_matches_bf16_rounded_oracle(name):
+    """Pins the bf16 KERNELS (as opposed to the bf16 arithmetic): the oracle with its rounding hook restates the
+    reference's algorithm with bf16 stores at the points where the engine rounds (input, weight shadow, activations,
+    activation gradients; fp32 accumulation, fp32 master weights and Adam).  On the first step - identical parameters
+    on both sides - every gradient tensor agrees to 1e-3 relative L2 (measured 2e-8 on the 6-layer stack, 7e-4 on the
+    10-layer one: fp32 summation order, MFMA vs BLAS, now and then moves one bf16 rounding by an ulp), against 0.06-0.15
+    vs the fp32 reference.  Later steps compare loss and gradient norm only: Adam normalises every element's step to
+    ~lr, so an element whose gradient is within rounding of zero moves +lr on one side and -lr on the other, ReLU masks
+    flip with it, and the two trajectories' GRADIENTS drift apart by 4-24 % rel. L2 within an epoch while their LOSS
+    curves stay within 1.3e-4 (tools/bf16_curve_dev.py prints both) - the same sensitivity that makes bf16 sit 15 %
+    from the fp32 gradients at layer 0."""
+    from oracle import dae_oracle as O
+    g = Golden(name)
+    m = g.meta
+    ad = FusedTrainerAdapter(g, "bf16")
+    orc = O.EmbeddingTrainer(g.params("init"), g.relu_flags(), m["lr"], m["weight_decay"], quant=O.bf16_round)
+    eng = ad.t.engine
+    for step, (idx, run) in enumerate(g.calls()[:9]):                      # the first epoch's nine optimizer steps
+        _, fmask = O.get_masks(g["binary_masks"], g["nb_missing_per_run"], g["mask_to_use"], 1, idx, run)
+        ro = orc.step(g["data"][idx], fmask)
+        eng.zero_metric_sums()
+        ad.t.train_batch(torch.tensor(idx, dtype=torch.int32, device=DEV), run=run)
+        sq, sqp, gsq, loss = eng.read_scalars()
+        first = step == 0
+        assert abs(loss - float(ro["loss"])) <= (1e-6 if first else 4e-4) * float(ro["loss"]), (step, loss, ro["loss"])
+        assert abs(math.sqrt(gsq) - float(ro["grad_norm"])) <= (1e-5 if first else 1e-2) * float(ro["grad_norm"]), (step, math.sqrt(gsq), ro["grad_norm"])
+        assert abs(sqp - float(ro["sq_partial"])) <= (1e-6 if first else 6e-4) * float(ro["sq_partial"])
+        if first:
+            for l, (gw, gb) in enumerate(orc.last_grads):                  # this step's gradients, every tensor
+                assert _rel_l2(eng.weight_grad(l).cpu().numpy(), gw) <= 2e-3, ("dW", l)
+                assert _rel_l2(eng.bias_grad(l).cpu().numpy(), gb) <= 2e-3, ("db", l)
+
+
+@pytest.mark.parametrize("name", ["embedding_wide_square", "embedding_wide_taper"])
+def test_fused_first_step_grads_bf16(name):
+    g = Golden(name)
+    ad = FusedTrainerAdapter(g, "bf16")
+    idx, run = g.calls()[0]
+    eng = ad.t.engine
+    batch = ad.t._batch(torch.tensor(idx, dtype=torch.int32, device=DEV), run)
+    hyper = eng.hyper(g.meta["lr"], g.meta["weight_decay"], 1.0, global_rows=len(idx))
+    eng.step_forward_loss(batch, hyper)
+    eng.step_backward(len(idx), 0, eng.L)
+    torch.cuda.synchronize()
+    for l, (gw, gb) in enumerate(g.list("grad0")):
+        assert _rel_l2(eng.weight_grad(l).cpu().numpy(), gw) <= BF16_GRAD0_REL_L2[name], ("dW", l)
+        assert _rel_l2(eng.bias_grad(l).cpu().numpy(), gb) <= BF16_GRAD0_REL_L2[name], ("db", l)
+
+
+@pytest.mark.parametrize("name", ["embedding_square", "embedding_wide_square", "embedding_wide_taper"])
+def test_fused_first_step_grads_f32(name):
+    g = Golden(name)
     ad = FusedTrainerAdapter(g, "f32")
     idx, run = g.calls()[0]
     eng = ad.t.engine
@@ -292,16 +405,19 @@ def test_bucketed_allreduce_path_on_rccl_single_rank(monkeypatch):
         mtu = rng.integers(0, S, (2 * B, 1)).astype(np.int32)
         outs = []
         for distributed in (False, True):
+            # clip at 100: the coefficient is exactly 1 on both paths (the fused step gathers sum g^2 in the slab reduces,
+            # the data-parallel step in one pass over the reduced gradients: different fp32 summation orders)
             tr = HipEmbeddingTrainer(sched, torch.tensor(data), torch.tensor(bm).to(torch.uint8), torch.tensor(mtu), 1e-3, 1e-4,
-                                     1.0, max_batch=B, precision="bf16", device=DEV, distributed=distributed, n_buckets=4)
+                                     100.0, max_batch=B, precision="bf16", device=DEV, distributed=distributed, n_buckets=4)
             tr.load_params(params)
             for s in range(3):
                 tr.train_batch(torch.arange(s * 64, s * 64 + B, dtype=torch.int32, device=DEV), run=0)
             outs.append(tr.engine.params.clone())
             if distributed:
                 assert tr.dp.always_reduce and len(tr.dp.buckets) == 4
-        # bias gradients are accumulated with float atomics (order varies run to run): compare to 1e-6
-        assert torch.allclose(outs[0], outs[1], rtol=0, atol=1e-6)
+        # no float atomics anywhere in the step (bias gradients: per-tile partial sums added in a fixed order):
+        # the bucketed path must reproduce the fused step bit for bit, bias block included
+        assert torch.equal(outs[0], outs[1])
     finally:
         dist.destroy_process_group()
 
@@ -346,8 +462,8 @@ def test_full_size_c3_gradient_is_additive_over_row_shards():
     """BASELINE config C3 (10 x Linear(1536,1536), batch 8192, bf16) through a size-independent property: with the loss
     scaled by the GLOBAL batch, grad(full batch) = grad(first half) + grad(second half) — what the data-parallel
     sharding relies on.  Rows are independent in the forward, so the only differences are fp32 summation order in the
-    weight-gradient GEMM (split-K ranges move) and the atomics of the bias sums.  Also: the bucketed no-join backward
-    (codae_step_backward_async) must give the joined backward's gradients exactly (weights) / to atomics order (biases)."""
+    weight-gradient GEMM (split-K ranges move) and of the bias partial sums.  Also: the bucketed no-join backward
+    (codae_step_backward_async) must give the joined backward's gradients EXACTLY, bias block included (no atomics)."""
     from codae.hip.engine import DaeEngine
     S, E, B, L = 3, 512, 8192, 10
     io = S * E
@@ -381,20 +497,48 @@ def test_full_size_c3_gradient_is_additive_over_row_shards():
     nw = eng.b_off[0]                                   # weights first, then the bias block
     assert float(full[:nw].abs().max()) > 0 and bool(torch.isfinite(full).all())
     bucketed = grads_of(0, B, buckets=[(6, 10), (3, 6), (1, 3), (0, 1)])
-    assert torch.equal(full[:nw], bucketed[:nw])
-    assert torch.allclose(full[nw:], bucketed[nw:], rtol=0, atol=1e-6)
+    assert torch.equal(full, bucketed)
+    assert torch.equal(full, grads_of(0, B))                  # and the same bits on a second run
     halves = grads_of(0, B // 2) + grads_of(B // 2, B)
     scale = float(full[:nw].abs().max())
     assert float((full[:nw] - halves[:nw]).abs().max()) <= 2e-3 * scale
     assert float((full[nw:] - halves[nw:]).abs().max()) <= 2e-3 * float(full[nw:].abs().max())
 
 
+def test_step_is_bitwise_deterministic_run_to_run():
+    """round 1's bias-gradient column sums used atomicAdd(float), so two runs of the product on the
+    same inputs differed in the last bits.  Now every reduction has a fixed order: 5 unsynchronised steps, twice, from
+    the same state -> identical parameters, Adam moments and loss, bit for bit (two-stream backward included)."""
+    from codae.train import HipEmbeddingTrainer
+    from oracle import dae_oracle as O
+    S, E, B = 3, 256, 2048
+    io = S * E
+    rng = np.random.default_rng(3)
+    N = 2 * B
+    data = rng.random((N, io), dtype=np.float32)
+    sched = O.layer_schedule(io, io, 2, 2, False, "embedding")
+    params = O.init_params(sched, rng)
+    bm, _, _ = O.corrupter_tables([{"size": E, "position": s * E} for s in range(S)], 1)
+    mtu = rng.integers(0, S, (N, 1)).astype(np.int32)
+    order = [torch.tensor(rng.permutation(N)[:B - 37 * s], dtype=torch.int32, device=DEV) for s in range(5)]   # ragged too
+    runs = []
+    for _ in range(2):
+        tr = HipEmbeddingTrainer(sched, torch.tensor(data), torch.tensor(bm).to(torch.uint8), torch.tensor(mtu), 1e-3, 1e-4, 1.0,
+                                 max_batch=B, precision="bf16", device=DEV)
+        tr.load_params(params)
+        for s in range(5):
+            tr.train_batch(order[s], run=0)
+        runs.append((tr.engine.params.clone(), tr.engine.adam_m.clone(), tr.engine.adam_v.clone(), tr.engine.read_scalars()))
+    for a, b in zip(runs[0][:3], runs[1][:3]):
+        assert torch.equal(a, b)
+    assert runs[0][3] == runs[1][3]
+
+
 def test_two_stream_step_matches_single_stream_over_many_steps(monkeypatch):
     """Race check for the step's stream choreography (backward on two streams, per-layer dA buffers, alternating slab
     buffers, tail wgrad on the caller's stream, transposed shadow refreshed on the side stream): 40 steps at a size that
     takes the big-tile kernels must track the same run with everything on ONE stream (CODAE_SINGLE_STREAM=1, where no
-    ordering can go wrong).  The two differ only by float-atomics order in the bias sums, which Adam turns into
-    +-lr flips of near-zero-gradient parameters: the loss curves agree to 1e-3 (measured 1e-4), a race gives gross errors."""
+    ordering can go wrong).  Without float atomics the two are the same arithmetic in the same order: identical bits."""
     from codae.train import HipEmbeddingTrainer
     from oracle import dae_oracle as O
     S, E, B, steps = 3, 256, 4096, 40
@@ -424,10 +568,8 @@ def test_two_stream_step_matches_single_stream_over_many_steps(monkeypatch):
         runs.append((losses, tr.engine.params.clone()))
     (la, pa), (lb, pb) = runs
     assert la[-1] < la[0]                                    # it trains
-    for x, y in zip(la, lb):
-        assert abs(x - y) <= 1e-3 * abs(x), (la, lb)
-    d = (pa - pb).abs()
-    assert float(d.max()) <= 2 * 1e-3 * steps and float(d.mean()) <= 1e-3, (float(d.max()), float(d.mean()))
+    assert la == lb, (la, lb)
+    assert torch.equal(pa, pb)
 
 
 @pytest.mark.parametrize("S,E,B", [(3, 64, 128), (3, 256, 4096)], ids=["small", "bigtile"])
@@ -455,7 +597,7 @@ def test_graph_replay_matches_eager_step(S, E, B):
             tr.train_batch(order[s], run=0)
         out.append((tr.engine.params.clone(), tr.engine.read_scalars()))
     (pa, sa), (pb, sb) = out
-    assert abs(sa[3] - sb[3]) <= 1e-4 * abs(sa[3]), (sa, sb)          # last loss (float-atomics order differs)
+    assert abs(sa[3] - sb[3]) <= 1e-5 * abs(sa[3]), (sa, sb)          # last loss
     d = (pa - pb).abs()
     assert float(d.mean()) <= 1e-5 and float(d.max()) <= 2 * 1e-3 * 6, (float(d.mean()), float(d.max()))
 

@@ -15,12 +15,12 @@ dy = (torch.randn(M, N, generator=g) * 1e-2).to(dev).bfloat16()
 h = (torch.rand(M, K, generator=g) - 0.3).to(dev).bfloat16()
 y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
 dx = torch.empty(M, K, device=dev, dtype=torch.bfloat16)
-db = torch.zeros(K, device=dev)
+db = torch.zeros(K, device=dev); dbws = torch.zeros((M + 127) // 128 * K, device=dev)
 dW = torch.empty(N, K, device=dev)
 slabs = torch.empty(8 * N * K, device=dev)
 st = hip.current_stream()
 def fwd(): hip.check(L.codae_linear_bf16(hip.ptr(x), hip.ptr(W), hip.ptr(b), hip.ptr(y), 0, M, N, K, 1, st))
-def dgrad(): hip.check(L.codae_dgrad_bf16(hip.ptr(dy), hip.ptr(W), hip.ptr(h), hip.ptr(dx), hip.ptr(db), M, N, K, st))
+def dgrad(): hip.check(L.codae_dgrad_bf16(hip.ptr(dy), hip.ptr(W), hip.ptr(h), hip.ptr(dx), hip.ptr(db), hip.ptr(dbws), M, N, K, st))
 def wgrad(): hip.check(L.codae_wgrad_bf16(hip.ptr(dy), hip.ptr(x), hip.ptr(dW), hip.ptr(slabs), slabs.numel() * 4, M, N, K, st))
 ops = {"fwd": fwd, "dgrad": dgrad, "wgrad(+reduce)": wgrad}
 cfgs = sys.argv[4].split(",") if len(sys.argv) > 4 else ["s", "b", "c", "q"]

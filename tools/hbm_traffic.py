@@ -1,6 +1,8 @@
 """profiles/hbm_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py.
 
-Usage: python tools/hbm_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [out.json]
+Usage: python tools/hbm_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [workload key] [out.json]
+(workload key as bench.py builds it: "<slots>x<emb>_b<batch>_<precision>", default 3x512_b8192_bf16; the entry of that
+workload is replaced, other workloads in the file are kept)
 bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (MI355X_MICROARCH.md, HBM section: FETCH_SIZE / WRITE_SIZE are
 in KiB and, on gfx950, FETCH_SIZE tallies the 128-B requests of wide coalesced reads at 64 B)."""
 import csv, json, sys, collections
@@ -55,8 +57,14 @@ def main():
                     "hits included")
     res["_algorithmic"] = {"gemm_fwd": 55.1e6, "gemm_dgrad": 80.3e6, "gemm_wgrad": 97.5e6}
     res["_source"] = "tools/hbm_traffic.py %s %s" % (sys.argv[1].split("/")[-1], sys.argv[2].split("/")[-1])
-    path = sys.argv[3] if len(sys.argv) > 3 else "profiles/hbm_traffic.json"
-    json.dump(res, open(path, "w"), indent=1)
+    wkey = sys.argv[3] if len(sys.argv) > 3 else "3x512_b8192_bf16"
+    path = sys.argv[4] if len(sys.argv) > 4 else "profiles/hbm_traffic.json"
+    try:
+        doc = json.load(open(path))
+    except Exception:
+        doc = {}
+    doc.setdefault("workloads", {})[wkey] = res
+    json.dump(doc, open(path, "w"), indent=1)
     for k, v in sorted(out.items()):
         print("%-12s %8.1f MB per launch (read %7.1f, written %7.1f; %d launches)" %
               (k, v["bytes_per_launch"] / 1e6, v["read"] / 1e6, v["written"] / 1e6, v["launches_sampled"]))
