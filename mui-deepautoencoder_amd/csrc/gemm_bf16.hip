@@ -284,10 +284,15 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
                 const int id = rowinfo[2 * (hh * HR + rr) + 1];
                 live[it] = rl < RL && j < g.N && r < HR && src_row >= 0;
                 const float* xp = L.data + (int64_t)(src_row >= 0 ? src_row : 0) * L.io + jc;
+#if defined(CODAE_LOSS_ABL) && (CODAE_LOSS_ABL & 1)     // timing-only ablation: no gather of the target rows
+                xa[it] = make_float4(0.5f, 0.25f, 0.125f, 0.75f); xb[it] = xa[it]; (void)xp; (void)tb; (void)id;
+                mk[it] = make_uint2(0x01010101u, 0x00010101u);
+#else
                 xa[it] = *reinterpret_cast<const float4*>(xp);
                 xb[it] = *reinterpret_cast<const float4*>(xp + 4);
                 const uint2 mv = *reinterpret_cast<const uint2*>(tb + (int64_t)id * L.io + jc);
                 mk[it] = masked ? mv : make_uint2(0x01010101u, 0x01010101u);
+#endif
             }
             if (((BM / WM) * wr) / HR == hh) {
 #pragma unroll
@@ -332,7 +337,11 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) cs[k] += gq[k];
                     }
+#if defined(CODAE_LOSS_ABL) && (CODAE_LOSS_ABL & 2)     // timing-only ablation: no dY stores (kept live)
+                    asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
+#else
                     *reinterpret_cast<uint4*>(Cb + (int64_t)i * g.ldc + j) = o;
+#endif
                 }
             }
             __syncthreads();
@@ -569,7 +578,8 @@ int gemm_bf16(const GemmBf16& g, hipStream_t s) {
     if (env().gemm_dbg) { GemmBf16 g2 = g; g2.dbg = env().gemm_dbg; return gemm_bf16_pipe(g2, 0, s); }
     if (g.loss.enabled) {
         const int t = gemm_bf16_tile_big(g.M, g.N, 1);
-        if (t) return launch_cfg<256, 192, 4, 2>(g, s);
+        if (t == 1) return launch_cfg<256, 192, 4, 2>(g, s);      // (CODAE_GEMM_TILE=b: round 1's fused-loss kernel)
+        if (t) return gemm_bf16_pipe(g, 1, s);                    // 8-wave pipelined kernel, loss from the accumulators
         return launch_cfg<128, 128, 2, 2>(g, s);
     }
     switch (gemm_bf16_tile_big(g.M, g.N, g.split_k, g.b_mode == OP_KS || g.c_f32)) {

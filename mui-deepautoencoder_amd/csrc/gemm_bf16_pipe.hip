@@ -115,19 +115,20 @@ __device__ __forceinline__ int ks_from_lds_block(int lds_block, int kr) {
     }
 }
 
-// Global source (at k = 0) of the 16 bytes lane `lane` of loader wave `w` places with its `it`-th LDS-DMA
-// instruction of half-tile h (instruction j = it * NW + w writes img + j * 1024 + lane * 16).  Everything here
-// is loop invariant: the K loop only adds tile * (64 elements | 64 rows) to these pointers.
+// Global source (at k = 0), as a BYTE OFFSET from the operand's base, of the 16 bytes lane `lane` of loader wave `w`
+// places with its `it`-th LDS-DMA instruction of half-tile h (instruction j = it * NW + w writes img + j * 1024 +
+// lane * 16).  Everything here is loop invariant; the K advance is wave-uniform and goes into the scalar base, so the
+// DMA instruction takes {SGPR base, 32-bit VGPR offset}: half the address registers of per-lane 64-bit pointers and no
+// 64-bit VALU add per issue (operands are < 4 GiB: checked at launch).
 template <int MODE, int RH, int S, int NW>
-__device__ __forceinline__ const bf16_t* half_src(const bf16_t* __restrict__ P, int64_t ld, int r0, int rmax, int h, int it,
-                                                  int w, int lane) {
+__device__ __forceinline__ uint32_t half_src(int64_t ld, int r0, int rmax, int h, int it, int w, int lane) {
     const int j = it * NW + w;
     if constexpr (MODE == OP_KC) {
         const int lr = j * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((lr >> 1) & 7);
         int grow = r0 + half_to_tile<S>(lr, h, RH);
         grow = grow < rmax ? grow : rmax - 1;
-        return P + (int64_t)grow * ld + c * 8;
+        return (uint32_t)(((int64_t)grow * ld + c * 8) * 2);
     } else {
         constexpr int CPR = RH / 8;
         const int q = j * 64 + lane;
@@ -136,7 +137,7 @@ __device__ __forceinline__ const bf16_t* half_src(const bf16_t* __restrict__ P, 
         const int lc = (ks_from_lds_block<RH>(cp >> 1, kr) * 2 + (cp & 1)) * 8;
         int col = r0 + half_to_tile<S>(lc, h, RH);
         col = col + 8 <= rmax ? col : rmax - 8;
-        return P + (int64_t)kr * ld + col;
+        return (uint32_t)(((int64_t)kr * ld + col) * 2);
     }
 }
 
@@ -161,20 +162,22 @@ __device__ __forceinline__ void settle(bf16x8 (&f)[N][2]) {
     }
 }
 
-// 8-element MFMA fragment: 16-wide tile `t` (local to the half image), k-step `s`.
-template <int MODE, int RH>
-__device__ __forceinline__ bf16x8 read_frag(const lds_char* img, int t, int s, int lane) {
+// 8-element MFMA fragment: 16-wide tile `t` (local to the half image), k-step S.
+template <int MODE, int RH, int S>
+__device__ __forceinline__ bf16x8 read_frag(const lds_char* img, int t, int lane) {
     if constexpr (MODE == OP_KC) {
         const int r = lane & 15, g = lane >> 4;
-        const int off = (16 * t + r) * 128 + (((4 * s + g) ^ (r >> 1)) << 4);
+        const int off = (16 * t + r) * 128 + (((4 * S + g) ^ (r >> 1)) << 4);
         const s16x8 v = *reinterpret_cast<const __attribute__((address_space(3))) s16x8*>(img + off);
         return __builtin_bit_cast(bf16x8, v);
     } else {
+        // the swizzle key depends on (kr & 3) and ((kr >> 3) & 1) only, i.e. not on the k-step: both k-steps read from
+        // ONE address register, the second through the instruction's offset field (half the address VGPRs)
         const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-        const int kr = 32 * s + 8 * g + q;
+        const int kr = 8 * g + q;
         const int off = kr * (2 * RH) + (ks_to_lds_block<RH>(t, kr) << 5) + 8 * p;
-        const s16x4 lo = lds_read_tr16<0>(img + off);
-        const s16x4 hi = lds_read_tr16<4 * 2 * RH>(img + off);
+        const s16x4 lo = lds_read_tr16<S * 32 * 2 * RH>(img + off);
+        const s16x4 hi = lds_read_tr16<S * 32 * 2 * RH + 4 * 2 * RH>(img + off);
         const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         return __builtin_bit_cast(bf16x8, v);
     }
@@ -186,7 +189,8 @@ constexpr int TIMELINE_WGS = 4096, TIMELINE_SLOTS = 6;
 __device__ unsigned long long g_timeline[TIMELINE_WGS * TIMELINE_SLOTS];
 
 // EPI (bf16 output only): 1 = forward epilogue (bias + ReLU), 2 = data-gradient epilogue (ReLU mask from the saved
-// activation + column sums = bias gradient), 0 = everything decided at run time.  Apart from trimming the forward's
+// activation + column sums = bias gradient), 3 = last forward layer of a training step with the MSE loss, its gradient
+// and the metric sums computed straight from the accumulators (g.loss), 0 = everything decided at run time.  Apart from trimming the forward's
 // epilogue this gives the forward and the data-gradient launches distinct kernel symbols in rocprofv3 traces.
 template <int BM, int BN, int WM, int WN, int NLB, int A_MODE, int B_MODE, bool C_F32, int DBG = 0, int EPI = 0>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4)
@@ -206,7 +210,9 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
     constexpr int NA = AHR / 8 / NLA, NB = BHR / 8 / NLB;
     static_assert(NLB <= NW && NLA <= NW && (AHR / 8) % NLA == 0 && (BHR / 8) % NLB == 0, "loader waves");
     static_assert(SM % 32 == 0 && SN % 32 == 0, "wave sub-tile must split into 16-wide half tiles");
-    __shared__ __attribute__((aligned(16))) char smem_raw[2 * BUF];
+    // (EPI = 3: + {dataset row, mask id} of the tile's rows; ONE array: a second __shared__ object beside an LDS-DMA
+    // staging array makes the compiler drain vmcnt in front of LDS reads)
+    __shared__ __attribute__((aligned(16))) char smem_raw[2 * BUF + (EPI == 3 ? BM * 8 : 0)];
     lds_char* smem = (lds_char*)smem_raw;
 
     const int lane = threadIdx.x & 63;
@@ -244,43 +250,22 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
             g_timeline[blockIdx.x * TIMELINE_SLOTS + 5] = xcc & 0xf;
         }
     }
-    // per-lane LDS-DMA source pointers at k = 0 (loop invariant) and the per-K-tile advance
-    const bool b_loader = (NLB == NW) || (w < NLB);
-    const bool a_loader = (NLA == NW) || (w < NLA);
-    const bf16_t* a_src[2][NA];
-    const bf16_t* b_src[2][NB];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int it = 0; it < NA; ++it) a_src[h][it] = half_src<A_MODE, AHR, SM, NLA>(g.A, g.lda, i0, g.M, h, it, a_loader ? w : 0, lane) + (A_MODE == OP_KC ? (int64_t)kt_begin * BK : (int64_t)kt_begin * BK * g.lda);
-#pragma unroll
-        for (int it = 0; it < NB; ++it) b_src[h][it] = half_src<B_MODE, BHR, SN, NLB>(g.B, g.ldb, j0, g.N, h, it, b_loader ? w : 0, lane) + (B_MODE == OP_KC ? (int64_t)kt_begin * BK : (int64_t)kt_begin * BK * g.ldb);
+    if constexpr (EPI == 3) {
+        // {dataset row or -1, mask id} per tile row, fetched once here (two dependent loads that would otherwise sit in
+        // front of the epilogue); published to the other waves by the K loop's barriers
+        const LossFuse& L = g.loss;
+        int* rowinfo = reinterpret_cast<int*>(smem_raw + 2 * BUF);
+        for (int r = threadIdx.x; r < BM; r += 64 * NW) {
+            const int i = i0 + r;
+            int src = -1, id = 0;
+            if (i < L.B && i < g.M) {
+                src = L.row_idx ? L.row_idx[i] : i;
+                if (L.mask_id != nullptr) id = L.mask_id[i];
+                else if (L.mask_to_use != nullptr) id = L.mask_to_use[(int64_t)src * L.nb_run + L.run];
+            }
+            rowinfo[2 * r] = src; rowinfo[2 * r + 1] = id;
+        }
     }
-    const int64_t a_step = A_MODE == OP_KC ? BK : (int64_t)BK * g.lda;
-    const int64_t b_step = B_MODE == OP_KC ? BK : (int64_t)BK * g.ldb;
-    // Loads past the last K-tile are issued anyway, re-reading the last tile into the (dead) region
-    // the schedule assigns: every phase stays one straight-line block the scheduler can interleave,
-    // and the vmcnt arithmetic is exact to the end (cost: ~2 extra K-tiles of L2-hit DMA per workgroup).
-    auto issue_a = [&](int tile, int h) {
-        if constexpr (!dbg_noload) {
-            if (a_loader) {
-                const int64_t adv = (int64_t)(tile < nkt ? tile : nkt - 1) * a_step;
-                lds_char* img = a_img(tile, h);
-#pragma unroll
-                for (int it = 0; it < NA; ++it) glds16(a_src[h][it] + adv, img + (it * NLA + w) * 1024);
-            }
-        }
-    };
-    auto issue_b = [&](int tile, int h) {
-        if constexpr (!dbg_noload) {
-            if (b_loader) {
-                const int64_t adv = (int64_t)(tile < nkt ? tile : nkt - 1) * b_step;
-                lds_char* img = b_img(tile, h);
-#pragma unroll
-                for (int it = 0; it < NB; ++it) glds16(b_src[h][it] + adv, img + (it * NLB + w) * 1024);
-            }
-        }
-    };
 
     f32x4 acc[2][TMH][2][TNH];
 #pragma unroll
@@ -292,19 +277,58 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
 #pragma unroll
                 for (int d = 0; d < TNH; ++d) acc[a][b][c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // The whole K loop, specialised at COMPILE time on the wave's loader roles (a wave-uniform property: with the
+    // 256 x 192 tile only 6 of the 8 waves carry B pieces).  Round 1 tested the roles inside every phase: 2-3 scalar
+    // branches per phase, each ending a basic block, so the B-piece issue of P2 / P4 sat in a block of its own in
+    // front of the phase's MFMAs instead of between them.  Now there is one branch in front of the loop.
+    auto k_loop = [&](auto al_tag, auto bl_tag) {
+    constexpr bool a_loader = decltype(al_tag)::value, b_loader = decltype(bl_tag)::value;
+    // per-lane LDS-DMA source pointers at k = 0 (loop invariant) and the per-K-tile advance
+    uint32_t a_src[2][NA], b_src[2][NB];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int it = 0; it < NA; ++it) a_src[h][it] = half_src<A_MODE, AHR, SM, NLA>(g.lda, i0, g.M, h, it, a_loader ? w : 0, lane);
+#pragma unroll
+        for (int it = 0; it < NB; ++it) b_src[h][it] = half_src<B_MODE, BHR, SN, NLB>(g.ldb, j0, g.N, h, it, b_loader ? w : 0, lane);
+    }
+    const int64_t a_step = (A_MODE == OP_KC ? BK : (int64_t)BK * g.lda) * 2;       // bytes per K-tile
+    const int64_t b_step = (B_MODE == OP_KC ? BK : (int64_t)BK * g.ldb) * 2;
+    const char* a_base = reinterpret_cast<const char*>(g.A) + kt_begin * a_step;
+    const char* b_base = reinterpret_cast<const char*>(g.B) + kt_begin * b_step;
+    // Loads past the last K-tile are issued anyway, re-reading the last tile into the (dead) region
+    // the schedule assigns: every phase stays one straight-line block the scheduler can interleave,
+    // and the vmcnt arithmetic is exact to the end (cost: ~2 extra K-tiles of L2-hit DMA per workgroup).
+    auto issue_a = [&](int tile, int h) {
+        if constexpr (!dbg_noload && a_loader) {
+            const char* base = a_base + (int64_t)(tile < nkt ? tile : nkt - 1) * a_step;      // wave-uniform
+            lds_char* img = a_img(tile, h);
+#pragma unroll
+            for (int it = 0; it < NA; ++it) glds16(base + a_src[h][it], img + (it * NLA + w) * 1024);
+        }
+    };
+    auto issue_b = [&](int tile, int h) {
+        if constexpr (!dbg_noload && b_loader) {
+            const char* base = b_base + (int64_t)(tile < nkt ? tile : nkt - 1) * b_step;
+            lds_char* img = b_img(tile, h);
+#pragma unroll
+            for (int it = 0; it < NB; ++it) glds16(base + b_src[h][it], img + (it * NLB + w) * 1024);
+        }
+    };
+
     bf16x8 a0x[TMH][2], a0y[TMH][2], a1[TMH][2], b0[TNH][2], b1[TNH][2];
 
     auto read_a = [&](bf16x8 (&dst)[TMH][2], int tile, int h) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int mt = 0; mt < TMH; ++mt) dst[mt][0] = read_frag<A_MODE, AHR, 0>(a_img(tile, h), wr * TMH + mt, lane);
 #pragma unroll
-            for (int mt = 0; mt < TMH; ++mt) dst[mt][s] = read_frag<A_MODE, AHR>(a_img(tile, h), wr * TMH + mt, s, lane);
+        for (int mt = 0; mt < TMH; ++mt) dst[mt][1] = read_frag<A_MODE, AHR, 1>(a_img(tile, h), wr * TMH + mt, lane);
     };
     auto read_b = [&](bf16x8 (&dst)[TNH][2], int tile, int h) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int nt = 0; nt < TNH; ++nt) dst[nt][0] = read_frag<B_MODE, BHR, 0>(b_img(tile, h), wc * TNH + nt, lane);
 #pragma unroll
-            for (int nt = 0; nt < TNH; ++nt) dst[nt][s] = read_frag<B_MODE, BHR>(b_img(tile, h), wc * TNH + nt, s, lane);
+        for (int nt = 0; nt < TNH; ++nt) dst[nt][1] = read_frag<B_MODE, BHR, 1>(b_img(tile, h), wc * TNH + nt, lane);
     };
     auto mma = [&](const bf16x8 (&a)[TMH][2], const bf16x8 (&b)[TNH][2], int mh, int nh) {
         if constexpr (dbg_nomma) {
@@ -331,9 +355,8 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
     // own LDS-DMA pieces that may still be in flight: CA A-halves + CB B-halves (per loader class of this wave)
     auto wait_dma = [&](auto ca, auto cb) {
         constexpr int CA = decltype(ca)::value, CB = decltype(cb)::value;
-        if (a_loader && b_loader) wait_vmcnt<CA * NA + CB * NB>();
-        else if (a_loader) wait_vmcnt<CA * NA>();
-        else if (b_loader) wait_vmcnt<CB * NB>();
+        constexpr int N = (a_loader ? CA * NA : 0) + (b_loader ? CB * NB : 0);
+        if constexpr (a_loader || b_loader) wait_vmcnt<N>();
     };
     auto wait_for_a = [&]() { wait_dma(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}); };
     auto wait_for_b = [&]() { wait_dma(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{}); };
@@ -356,7 +379,7 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
     // transposed reads of a k-strided operand are waited for in full (settle() follows the barrier)
     constexpr int KEEP_A = A_MODE == OP_KC ? 2 * TMH : 0, KEEP_B = B_MODE == OP_KC ? 2 * TNH : 0;
     // one K-tile; `a0` holds A0(t), `a0n` receives A0(t+1).  Reads of a tile past the end fetch the
-    // dummy re-load and are never multiplied.
+    // dummy re-load and are never multiplied (see the settle block behind the loop).
     auto ktile = [&](int t, bf16x8 (&a0)[TMH][2], bf16x8 (&a0n)[TMH][2]) {
         // P1: A0 x B0
         wait_for_a();
@@ -397,12 +420,195 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
         ktile(t + 1, a0y, a0x);
     }
     if (t < nkt) ktile(t, a0x, a0y);
+    if constexpr (A_MODE == OP_KS || B_MODE == OP_KS) {
+        // The last K-tile's reads of tile t+1 are dummies nobody multiplies.  For a k-strided operand they are
+        // inline-asm reads, so without a use the compiler would recycle their destination registers at once (round 1's
+        // code object did: as address temporaries, while the LDS data was still on its way - a write-after-write race
+        // the s_waitcnt bookkeeping cannot see; tools/check_isa.py found it).  Waiting for them and naming the
+        // registers here keeps them reserved until the data has landed.  (Peeling the last K-tile instead, or skipping
+        // the reads under a branch, made the compiler copy fragment registers across the control-flow merge - moves of
+        // registers with reads in flight, the same race - and spill.)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (A_MODE == OP_KS) { settle(a0x); settle(a0y); }      // (a1 / b1 are always multiplied)
+        if constexpr (B_MODE == OP_KS) settle(b0);
+    }
+    };   // k_loop
+    {
+        const bool al = (NLA == NW) || (w < NLA), bl = (NLB == NW) || (w < NLB);
+        if constexpr (NLA == NW && NLB == NW) k_loop(std::true_type{}, std::true_type{});
+        else if constexpr (NLA == NW) { if (bl) k_loop(std::true_type{}, std::true_type{}); else k_loop(std::true_type{}, std::false_type{}); }
+        else {
+            if (al && bl) k_loop(std::true_type{}, std::true_type{});
+            else if (al) k_loop(std::true_type{}, std::false_type{});
+            else if (bl) k_loop(std::false_type{}, std::true_type{});
+            else k_loop(std::false_type{}, std::false_type{});
+        }
+    }
     wait_vmcnt<0>();        // the trailing dummy loads must not outlive the kernel's use of LDS
     stamp(2);
 
     // ---- epilogue: lane holds C[i][j .. j+3] of each 16 x 16 tile (swapped MFMA operands)
     const int li = lane & 15, g4 = (lane >> 4) * 4;
     phase_barrier();          // every wave is past its last fragment read and every DMA has landed: LDS is free
+    if constexpr (EPI == 3) {
+        // Last forward layer of a training step (train_dae_on_embedding.py:206-223): y = acc + bias stays in registers.
+        // Each lane holds C[i][j .. j+3] of its 16 x 16 tiles, so it fetches the 16 B of the target row x (gathered
+        // dataset row, fp32) and the 4 mask bytes that face them - unconditional loads from clamped addresses, one row
+        // half of the wave at a time - computes dy = 2 (y - x) / n, the metric sums and the column sums of dy, and only
+        // the bf16 dy tile goes through LDS (one pass, whole rows out, 16 B per lane).  Round 1 staged the fp32 y tile
+        // through LDS in two halves and re-read it row by row: 19 us of LDS / VALU work on top of the HBM time.
+        const LossFuse& L = g.loss;
+        const int* rowinfo = reinterpret_cast<const int*>(smem_raw + 2 * BUF);
+        const bool masked = (L.mask_id != nullptr) || (L.mask_to_use != nullptr);
+        const uint8_t* tb = masked ? L.table : reinterpret_cast<const uint8_t*>(L.data);     // (unmasked: any valid bytes)
+        constexpr int NT = 64 * NW;
+        constexpr int PITCH = BN * 2 + 16;
+        static_assert(BM * PITCH <= 2 * BUF, "output tile must fit in the staging buffers");
+        float sq = 0.f, sqp = 0.f;
+        float cs[2][TNH][4];
+        int jcl[2][TNH];                // clamped global column of the lane's 4-column group; -1 flag kept in jok
+        bool jok[2][TNH];
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int nt = 0; nt < TNH; ++nt) {
+                const int j = j0 + nh * BHR + wc * (SN / 2) + 16 * nt + g4;
+                jok[nh][nt] = j < g.N;
+                jcl[nh][nt] = jok[nh][nt] ? j : 0;
+                const float4 bj = load_bias4(g.bias, g.A, j, g.N);          // y = acc + bias, in place (frees 24 registers)
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                    for (int mt = 0; mt < TMH; ++mt) {
+                        acc[mh][mt][nh][nt][0] += bj.x; acc[mh][mt][nh][nt][1] += bj.y;
+                        acc[mh][mt][nh][nt][2] += bj.z; acc[mh][mt][nh][nt][3] += bj.w;
+                    }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cs[nh][nt][k] = 0.f;
+            }
+        // a tile that lies wholly inside the N columns (the usual case) addresses the lane's 6 column groups as ONE
+        // pointer + compile-time offsets (instruction immediates); per-group clamped addresses cost 48 more registers
+        const int jbase = j0 + wc * (SN / 2) + g4;
+        auto loss_rows = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh) {
+                float4 xv[TMH][2][TNH];
+                uint32_t mk[TMH][2][TNH];
+                bool live[TMH];
+#pragma unroll
+                for (int mt = 0; mt < TMH; ++mt) {
+                    const int il = mh * AHR + wr * (SM / 2) + 16 * mt + li;
+                    const int src = rowinfo[2 * il], id = rowinfo[2 * il + 1];
+                    live[mt] = src >= 0;
+                    const float* xrow = L.data + (int64_t)(src >= 0 ? src : 0) * L.io;
+                    const uint8_t* mrow = tb + (int64_t)id * L.io;
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                        for (int nt = 0; nt < TNH; ++nt) {
+                            const int off = FULL ? jbase + (nh * BHR + 16 * nt) : jcl[nh][nt];
+                            xv[mt][nh][nt] = *reinterpret_cast<const float4*>(xrow + off);
+                            const uint32_t mv = *reinterpret_cast<const uint32_t*>(mrow + off);
+                            mk[mt][nh][nt] = masked ? mv : 0x01010101u;
+                        }
+                }
+#pragma unroll
+                for (int mt = 0; mt < TMH; ++mt) {
+                    const int il = mh * AHR + wr * (SM / 2) + 16 * mt + li;
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                        for (int nt = 0; nt < TNH; ++nt) {
+                            const int jl = nh * BHR + wc * (SN / 2) + 16 * nt + g4;
+                            const f32x4 a = acc[mh][mt][nh][nt];
+                            const float4 x = xv[mt][nh][nt];
+                            const float yv[4] = {a[0], a[1], a[2], a[3]};
+                            const float xs[4] = {x.x, x.y, x.z, x.w};
+                            const bool on = live[mt] && (FULL || jok[nh][nt]);
+                            float gq[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float d = on ? xs[k] - yv[k] : 0.f;
+                                const float se = d * d;
+                                sq += se;
+                                sqp += ((mk[mt][nh][nt] >> (8 * k)) & 0xffu) == 0 ? se : 0.f;
+                                gq[k] = -2.f * d * L.inv_n;
+                                cs[nh][nt][k] += gq[k];
+                            }
+                            u32x2 o;
+                            o[0] = pack_bf16x2(gq[0], gq[1]);
+                            o[1] = pack_bf16x2(gq[2], gq[3]);
+                            *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(smem + il * PITCH + jl * 2) = o;
+                        }
+                }
+                // (keeps the second half's gather registers from being live beside the first half's: 256-register budget)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (j0 + BN <= g.N) loss_rows(std::true_type{}); else loss_rows(std::false_type{});
+        phase_barrier();
+        {
+            constexpr int CH = BN / 8, RL = NT / CH;
+            const int c = threadIdx.x % CH, rl = threadIdx.x / CH;
+            const int j = j0 + c * 8;
+            if (rl < RL && j < g.N) {
+                bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
+                for (int r = rl; r < BM; r += RL) {
+                    const int i = i0 + r;
+                    if (i >= g.M) break;
+                    const u32x4 lv = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(smem + r * PITCH + c * 16);
+                    *reinterpret_cast<uint4*>(Cb + (int64_t)i * g.ldc + j) = make_uint4(lv[0], lv[1], lv[2], lv[3]);
+                }
+            }
+        }
+        // metric sums: lanes -> wave -> workgroup -> one double atomic each (exact: the addends are fp32)
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) { sq += __shfl_xor(sq, o2); sqp += __shfl_xor(sqp, o2); }
+        // column sums of dy (the last bias gradient): the 16 row-lanes of a column group, then the WM wave rows
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int nt = 0; nt < TNH; ++nt)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float v = cs[nh][nt][k];
+                    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                    cs[nh][nt][k] = v;
+                }
+        phase_barrier();          // the staged dy tile has been read by everyone: LDS is scratch again
+        float* red = reinterpret_cast<float*>(smem_raw);          // [WM][BN] column partials, then 2 * NW block partials
+        static_assert((WM * BN + 2 * NW) * 4 <= 2 * BUF, "reduction scratch must fit");
+        if (li == 0) {
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int nt = 0; nt < TNH; ++nt) {
+                    const int jl = nh * BHR + wc * (SN / 2) + 16 * nt + g4;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) red[wr * BN + jl + k] = cs[nh][nt][k];
+                }
+        }
+        float* wsum = red + WM * BN;
+        if (lane == 0) { wsum[2 * w] = sq; wsum[2 * w + 1] = sqp; }
+        phase_barrier();
+        if (threadIdx.x == 0) {
+            float a = 0.f, b2 = 0.f;
+            for (int ww = 0; ww < NW; ++ww) { a += wsum[2 * ww]; b2 += wsum[2 * ww + 1]; }
+            atomicAdd(&L.scalars[CODAE_S_SQ_FULL], (double)a);
+            atomicAdd(&L.scalars[CODAE_S_STEP_SQ], (double)a);
+            if (masked) atomicAdd(&L.scalars[CODAE_S_SQ_PARTIAL], (double)b2);
+        }
+        if (g.colsum_part != nullptr) {
+            for (int col = threadIdx.x; col < BN; col += NT) {
+                float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < WM; ++r) sum += red[r * BN + col];
+                if (j0 + col < g.N) g.colsum_part[(int64_t)tm * g.N + j0 + col] = sum;
+            }
+        }
+        return;
+    }
     if constexpr (!C_F32 && !dbg_nostore) {
         // bf16 output through LDS, whole rows, 16 B per lane (see gemm_bf16.hip); mask + bias-grad sums ride along
         constexpr int NT = 64 * NW;
@@ -531,12 +737,19 @@ int launch_pipe(const GemmBf16& g, hipStream_t s) {
     const int kt_total = g.K / BK;
     const int64_t nwg = (int64_t)tiles_m * tiles_n * g.split_k;
     CODAE_REQUIRE(nwg < (1 << 30), "gemm_bf16: grid too large");
+    // LDS-DMA sources are addressed as {scalar base, 32-bit lane offset}
+    CODAE_REQUIRE((int64_t)(g.a_mode == OP_KC ? g.M : g.K) * g.lda * 2 < (int64_t)1 << 32 &&
+                      (int64_t)(g.b_mode == OP_KC ? g.N : g.K) * g.ldb * 2 < (int64_t)1 << 32,
+                  "gemm_bf16: operand larger than 4 GiB");
     dim3 grid((unsigned)nwg), block(64 * WM * WN);
 #define LAUNCH(AM, BMODE, CF, EP) \
     hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, WM, WN, NLB, AM, BMODE, CF, 0, EP>), grid, block, 0, s, g, tiles_n, tiles_m * tiles_n, kt_total)
 #define LAUNCH_BF16(AM, BMODE) do { if (bwd_epi) LAUNCH(AM, BMODE, false, 2); else LAUNCH(AM, BMODE, false, 1); } while (0)
     const bool bwd_epi = g.relu_src != nullptr || g.colsum_part != nullptr;
-    if (g.a_mode == OP_KC && g.b_mode == OP_KC) { if (g.c_f32) LAUNCH(OP_KC, OP_KC, true, 0); else LAUNCH_BF16(OP_KC, OP_KC); }
+    if (g.loss.enabled) {
+        if constexpr (WM * WN == 8) LAUNCH(OP_KC, OP_KC, false, 3);
+        else { set_error("gemm_bf16: fused loss is built for the 8-wave pipelined tile only"); return CODAE_E_UNSUPPORTED; }
+    } else if (g.a_mode == OP_KC && g.b_mode == OP_KC) { if (g.c_f32) LAUNCH(OP_KC, OP_KC, true, 0); else LAUNCH_BF16(OP_KC, OP_KC); }
     else if (g.a_mode == OP_KC && g.b_mode == OP_KS) { if (g.c_f32) LAUNCH(OP_KC, OP_KS, true, 0); else LAUNCH_BF16(OP_KC, OP_KS); }
     else if (g.a_mode == OP_KS && g.b_mode == OP_KS) { if (g.c_f32) LAUNCH(OP_KS, OP_KS, true, 0); else LAUNCH_BF16(OP_KS, OP_KS); }
     else { set_error("gemm_bf16: operand mode combination not built"); return CODAE_E_UNSUPPORTED; }

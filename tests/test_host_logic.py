@@ -277,3 +277,50 @@ def test_epoch_sampler_matches_torch_dataloader_order():
     mine = SubsetEpochSampler(subset, 16)
     got = [b.tolist() for _ in range(2) for b in mine]
     assert got == ref and len(mine) == 5
+
+
+def _load_check_isa():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_isa", os.path.join(ROOT, "tools", "check_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_isa_guard_passes_on_the_built_library():
+    """tools/check_isa.py (run by build()): every bf16 GEMM kernel of the code object that ships keeps its asm-issued
+    transposed LDS reads behind an s_waitcnt, has no vmcnt(0) in a pipelined K loop and no scratch."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_isa.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " 0 failing" in r.stdout and "k-strided pipelined instantiations" in r.stdout
+
+
+def test_isa_guard_detects_the_hazards_it_exists_for():
+    """The checker itself, on hand-written instruction streams: (a) an MFMA that consumes a transposed read before the
+    covering lgkmcnt wait, (b) a VALU write to a register whose transposed read is still in flight (what round 1's
+    code object did with the dead last-tile reads), (c) vmcnt(0) inside a pipelined K loop; and a clean loop passes."""
+    C = _load_check_isa()
+    name = "gemm_bf16_pipe_kernel<256, 192, 4, 2, 6, 1, 1, 1, 0, 0>"
+
+    def kernel(body):
+        ins = [(0x100, "s_nop", "0")]
+        a = 0x104
+        for op, args in body:
+            ins.append((a, op, args)); a += 4
+        ins.append((a, "s_cbranch_scc1", "65000 <k+0x4>"))
+        return ins
+
+    clean = [("ds_read_b64_tr_b16", "v[10:11], v5"), ("ds_read_b64_tr_b16", "v[12:13], v5 offset:768"),
+             ("s_waitcnt", "vmcnt(6)"), ("s_waitcnt", "lgkmcnt(0)"), ("s_barrier", ""),
+             ("v_mfma_f32_16x16x32_bf16", "v[0:3], v[10:13], v[20:23], v[0:3]")]
+    assert C.check_kernel("k", name, kernel(clean)) == []
+    early = [clean[0], clean[1], clean[5], clean[3]]
+    assert any("touches" in e for e in C.check_kernel("k", name, kernel(early)))
+    one_left = [clean[0], clean[1], ("s_waitcnt", "lgkmcnt(1)"), clean[5]]       # the younger read is still in flight
+    assert any("touches" in e for e in C.check_kernel("k", name, kernel(one_left)))
+    waw = [clean[0], ("v_add_u32_e32", "v10, 32, v7"), clean[3], clean[5]]
+    assert any("v_add_u32_e32" in e for e in C.check_kernel("k", name, kernel(waw)))
+    drained = clean[:2] + [("s_waitcnt", "vmcnt(0)")] + clean[3:]
+    assert any("vmcnt(0)" in e for e in C.check_kernel("k", name, kernel(drained)))
