@@ -127,7 +127,9 @@ struct LossFuse {
     int io;
     int B;                        // valid batch rows; rows in [B, M) get dy = 0
     float inv_n;                  // 1 / (global rows * io)
-    double* scalars;
+    double* parts;                // [workgroups][2]: each workgroup's {sum (x-y)^2, sum (1-m)(x-y)^2}, plain stores; added up
+                                  // in index order by launch_finish_loss (256 same-address double atomics cost the
+                                  // kernel ~10 us of serialised tail, and their order is not reproducible)
 };
 
 struct GemmBf16 {
@@ -145,6 +147,7 @@ struct GemmBf16 {
 };
 bool gemm_bf16_supported(int M, int N, int K);
 int gemm_bf16_colsum_rows(const GemmBf16& g);   // rows of colsum_part this launch writes (= its tiles along M)
+int gemm_bf16_loss_parts(const GemmBf16& g);    // workgroups of the fused-loss launch = rows of LossFuse::parts
 int gemm_bf16(const GemmBf16& g, hipStream_t s);
 int gemm_bf16_pipe(const GemmBf16& g, int cfg, hipStream_t s);   // gemm_bf16_pipe.hip
 
@@ -156,8 +159,9 @@ int launch_expand_masks(const int32_t* mask_id, const uint8_t* table, const int3
                         int k_max, float* masks_out, float* fmask_out, hipStream_t s);
 // y fp32 [B][io]; x gathered from batch; writes dy (fp32 or bf16), metric sums, optional colsum_part
 // [mse_loss_colsum_rows(B)][io] (partial sums of the last bias gradient, one row per block)
+// loss_parts [mse_loss_colsum_rows(B)][2]: per-block metric sums (see LossFuse::parts)
 int launch_mse_loss(const codae_batch* b, const float* y, void* dy, int dy_bf16, float inv_n, float* colsum_part,
-                    double* scalars, int want_grad, hipStream_t s);
+                    double* loss_parts, int want_grad, hipStream_t s);
 int mse_loss_colsum_rows(int B);
 int launch_mse_dense(const float* x, const float* y, const float* fmask, float* dy, int64_t n, float inv_n,
                      double* scalars, hipStream_t s);
@@ -181,7 +185,9 @@ int gemm_bf16_timeline(unsigned long long* host_out, int n_wg);   // CODAE_GEMM_
 // sumsq != null: += sum out^2 (slot-scattered)
 int launch_reduce_slabs(const float* slabs, int n_slabs, int64_t slab_stride, float* out, int64_t n, double* sumsq,
                         hipStream_t s);
-int launch_finish_loss(double* scalars, double inv_n, hipStream_t s);
+// parts != null: SQ_FULL += sum parts[i][0], SQ_PARTIAL += sum parts[i][1] (fixed order) and the step's loss from
+// them; parts == null: the step's sum was accumulated in scalars[STEP_SQ] (dense stand-alone loss)
+int launch_finish_loss(double* scalars, double inv_n, hipStream_t s, const double* parts = nullptr, int n_parts = 0);
 int launch_cast_f32(const bf16_t* src, float* dst, int64_t n, hipStream_t s);
 // out[n] = sum_m src[m][n], rows added in index order (deterministic; stand-alone primitive)
 int launch_colsum_f32(const float* src, int M, int N, float* out, hipStream_t s);

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(NT) void mse_loss_kernel(const float* __restrict__ 
                                                       const uint8_t* __restrict__ table, int B, int io,
                                                       const float* __restrict__ y, void* __restrict__ dy,
                                                       float inv_n, float* __restrict__ colsum_part,
-                                                      double* __restrict__ scalars, int want_grad,
+                                                      double* __restrict__ loss_parts, int want_grad,
                                                       const int32_t* __restrict__ mask_to_use, int nb_run, int run) {
     __shared__ float red[4];
     const bool masked = (mask_id != nullptr) || (mask_to_use != nullptr);
@@ -247,9 +247,8 @@ __global__ __launch_bounds__(NT) void mse_loss_kernel(const float* __restrict__ 
     const float bsq = block_sum(sq, red);
     const float bsqp = block_sum(sqp, red);
     if (threadIdx.x == 0) {
-        atomicAdd(&scalars[CODAE_S_SQ_FULL], (double)bsq);
-        atomicAdd(&scalars[CODAE_S_STEP_SQ], (double)bsq);
-        if (masked) atomicAdd(&scalars[CODAE_S_SQ_PARTIAL], (double)bsqp);
+        loss_parts[2 * blockIdx.x] = (double)bsq;
+        loss_parts[2 * blockIdx.x + 1] = masked ? (double)bsqp : 0.0;
     }
 }
 
@@ -275,16 +274,33 @@ __global__ __launch_bounds__(NT) void mse_dense_kernel(const float* __restrict__
     }
 }
 
-// LAST_LOSS = STEP_SQ * inv_n ; reset the per-step accumulators
-__global__ void finish_loss_kernel(double* scalars, double inv_n) {
-    if (blockIdx.x == 0) {
-        if (threadIdx.x == 0) {
-            scalars[CODAE_S_LAST_LOSS] = scalars[CODAE_S_STEP_SQ] * inv_n;
-            scalars[CODAE_S_STEP_SQ] = 0.0;
-            scalars[CODAE_S_GRAD_SQ] = 0.0;
+// Per-workgroup metric sums -> the epoch accumulators (added in index order: deterministic); LAST_LOSS = step sum * inv_n;
+// reset the per-step accumulators.  One block.
+__global__ __launch_bounds__(NT) void finish_loss_kernel(double* scalars, double inv_n, const double* __restrict__ parts,
+                                                         int n_parts) {
+    __shared__ double red[2][NT];
+    if (parts != nullptr) {
+        double a = 0.0, b = 0.0;
+        for (int i = threadIdx.x; i < n_parts; i += NT) { a += parts[2 * i]; b += parts[2 * i + 1]; }
+        red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
+        __syncthreads();
+        for (int o = NT / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+            __syncthreads();
         }
-        if (threadIdx.x < CODAE_S_N_SLOTS) scalars[CODAE_S_GRAD_SQ_SLOTS + threadIdx.x] = 0.0;
     }
+    if (threadIdx.x == 0) {
+        double step = scalars[CODAE_S_STEP_SQ];
+        if (parts != nullptr) {
+            step = red[0][0];
+            scalars[CODAE_S_SQ_FULL] += red[0][0];
+            scalars[CODAE_S_SQ_PARTIAL] += red[1][0];
+        }
+        scalars[CODAE_S_LAST_LOSS] = step * inv_n;
+        scalars[CODAE_S_STEP_SQ] = 0.0;
+        scalars[CODAE_S_GRAD_SQ] = 0.0;
+    }
+    if (threadIdx.x < CODAE_S_N_SLOTS) scalars[CODAE_S_GRAD_SQ_SLOTS + threadIdx.x] = 0.0;
 }
 
 // ---- a7: sum g^2 (clip_grad_norm_, train_dae_on_embedding.py:213) ---------------------------
@@ -552,8 +568,8 @@ int launch_expand_masks(const int32_t* mask_id, const uint8_t* table, const int3
 int mse_loss_colsum_rows(int B) { return (B + LOSS_ROWS - 1) / LOSS_ROWS; }
 
 int launch_mse_loss(const codae_batch* b, const float* y, void* dy, int dy_bf16, float inv_n, float* colsum_part,
-                    double* scalars, int want_grad, hipStream_t s) {
-    CODAE_REQUIRE(b && b->data && y && scalars && b->B > 0 && b->io > 0, "mse_loss: bad args");
+                    double* loss_parts, int want_grad, hipStream_t s) {
+    CODAE_REQUIRE(b && b->data && y && loss_parts && b->B > 0 && b->io > 0, "mse_loss: bad args");
     CODAE_REQUIRE(!want_grad || dy, "mse_loss: gradient requested without dy");
     const bool masked = b->mask_id || b->mask_to_use;
     CODAE_REQUIRE(!masked || b->mask_table, "mse_loss: mask ids without mask_table");
@@ -561,7 +577,7 @@ int launch_mse_loss(const codae_batch* b, const float* y, void* dy, int dy_bf16,
                      (!masked || (reinterpret_cast<uintptr_t>(b->mask_table) & 3) == 0);
     const int grid = (b->B + LOSS_ROWS - 1) / LOSS_ROWS;
 #define ML(V, O) hipLaunchKernelGGL((mse_loss_kernel<V, O>), dim3(grid), dim3(NT), 0, s, b->data, b->row_idx, \
-                                    b->mask_id, b->mask_table, b->B, b->io, y, dy, inv_n, colsum_part, scalars, want_grad, \
+                                    b->mask_id, b->mask_table, b->B, b->io, y, dy, inv_n, colsum_part, loss_parts, want_grad, \
                                     b->mask_to_use, b->nb_run, b->run)
     if (vec && dy_bf16) ML(true, true);
     else if (vec) ML(true, false);
@@ -580,8 +596,8 @@ int launch_mse_dense(const float* x, const float* y, const float* fmask, float* 
     return CODAE_OK;
 }
 
-int launch_finish_loss(double* scalars, double inv_n, hipStream_t s) {
-    hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(64), 0, s, scalars, inv_n);
+int launch_finish_loss(double* scalars, double inv_n, hipStream_t s, const double* parts, int n_parts) {
+    hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(NT), 0, s, scalars, inv_n, parts, parts ? n_parts : 0);
     CODAE_LAUNCH_CHECK();
     return CODAE_OK;
 }

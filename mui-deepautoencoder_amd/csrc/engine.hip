@@ -75,6 +75,8 @@ struct codae_engine {
     // produces that layer's activation gradient; parts_pending[l] = rows waiting for finish_bias (0 = none)
     std::vector<int64_t> part_off;
     int64_t part_floats = 0;
+    int64_t loss_part_off = 0;       // (floats, 8-byte aligned) per-workgroup metric sums of the loss kernels
+    int loss_part_cap = 0;
     mutable std::vector<int> parts_pending;
     // optional per-launch hipEvent pairs (codae_profile_begin / _end)
     // backward on two streams: the weight-gradient GEMMs (+ slab reduce) run on `side`, concurrently with
@@ -179,6 +181,9 @@ inline void* act_ptr(const codae_engine* e, const codae_buffers* b, int l) {
     return reinterpret_cast<char*>(b->acts) + e->act_off[l];
 }
 inline float* part_ptr(const codae_engine* e, const codae_buffers* b, int l) { return b->bias_parts + e->part_off[l]; }
+inline double* loss_parts_ptr(const codae_engine* e, const codae_buffers* b) {
+    return reinterpret_cast<double*>(b->bias_parts + e->loss_part_off);
+}
 inline void* dact_ptr(const codae_engine* e, const codae_buffers* b, int l) {
     return reinterpret_cast<char*>(b->dacts) + (int64_t)(l % e->n_dact) * e->dact_one;   // see backward_range
 }
@@ -527,6 +532,14 @@ int codae_create(const codae_spec* spec, codae_handle* out) {
         const int64_t rows_cap = (l == e->L - 1) ? (e->max_rows + 31) / 32 : (e->max_rows + 63) / 64;
         e->part_floats += round_up(rows_cap * (int64_t)e->out[l], 64);
     }
+    {   // + the loss kernels' per-workgroup metric sums: [workgroups][2] doubles
+        const int io = e->out[e->L - 1];
+        const int by_rows = (e->max_rows + 31) / 32;                                             // stand-alone loss kernel
+        const int by_tiles = ((e->max_rows + 127) / 128) * ((io + 127) / 128);                   // fused into the last GEMM
+        e->loss_part_cap = by_rows > by_tiles ? by_rows : by_tiles;
+        e->loss_part_off = e->part_floats;
+        e->part_floats += round_up((int64_t)e->loss_part_cap * 4, 64);
+    }
     e->slab_bytes = 0;
     for (int l = 0; l < e->L; ++l) {
         int s = 1;
@@ -685,7 +698,7 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
     CODAE_REQUIRE(batch->io == h->in[0] && batch->io == h->out[h->L - 1], "batch.io %d does not match the model (%d -> %d)",
                   batch->io, h->in[0], h->out[h->L - 1]);
     CODAE_REQUIRE(b->grads && b->dacts && b->scalars, "codae_step_forward_loss: grads / dacts / scalars missing");
-    CODAE_REQUIRE(hyper == nullptr || b->bias_parts, "codae_step_forward_loss: bias_parts missing");
+    CODAE_REQUIRE(b->bias_parts, "codae_step_forward_loss: bias_parts missing");
     if (h->prof_on) ++h->prof_step;
     hipStream_t s = (hipStream_t)stream;
     const int B = batch->B, L = h->L;
@@ -717,7 +730,9 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
             g.loss.enabled = 1; g.loss.data = batch->data; g.loss.row_idx = batch->row_idx; g.loss.mask_id = batch->mask_id;
             g.loss.mask_to_use = batch->mask_to_use; g.loss.nb_run = batch->nb_run; g.loss.run = batch->run;
             g.loss.table = batch->mask_table; g.loss.io = batch->io; g.loss.B = B; g.loss.inv_n = (float)(1.0 / n_glob);
-            g.loss.scalars = b->scalars;
+            g.loss.parts = loss_parts_ptr(h, b);
+            const int n_loss_parts = gemm_bf16_loss_parts(g);
+            CODAE_REQUIRE(n_loss_parts <= h->loss_part_cap, "fused loss: %d workgroups exceed the partial-sum rows (%d)", n_loss_parts, h->loss_part_cap);
             {
                 ProfScope prof(h, CODAE_K_LOSS, s);     // last layer + loss in one launch: its own class, not a plain forward GEMM
                 rc = gemm_bf16(g, s);
@@ -725,7 +740,7 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
             if (rc) return rc;
             h->parts_pending[l] = gemm_bf16_colsum_rows(g);
             h->norm_scalars_zero = true;
-            return launch_finish_loss(b->scalars, 1.0 / ((double)B * batch->io), s);
+            return launch_finish_loss(b->scalars, 1.0 / ((double)B * batch->io), s, loss_parts_ptr(h, b), n_loss_parts);
         }
         rc = last ? run_linear(h, b, l, act_ptr(h, b, l), y, true, B, s)
                   : run_linear(h, b, l, act_ptr(h, b, l), act_ptr(h, b, l + 1), false, rows, s);
@@ -740,16 +755,16 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
         {
             ProfScope prof(h, CODAE_K_LOSS, s);
             rc = launch_mse_loss(batch, y, dact_ptr(h, b, L - 1), bf, (float)(1.0 / n_glob), part_ptr(h, b, L - 1),
-                                 b->scalars, 1, s);
+                                 loss_parts_ptr(h, b), 1, s);
         }
         if (rc) return rc;
         h->parts_pending[L - 1] = mse_loss_colsum_rows(B);
         h->norm_scalars_zero = true;
-        return launch_finish_loss(b->scalars, 1.0 / ((double)B * batch->io), s);
+        return launch_finish_loss(b->scalars, 1.0 / ((double)B * batch->io), s, loss_parts_ptr(h, b), mse_loss_colsum_rows(B));
     }
-    rc = launch_mse_loss(batch, y, nullptr, 0, 0.f, nullptr, b->scalars, 0, s);
+    rc = launch_mse_loss(batch, y, nullptr, 0, 0.f, nullptr, loss_parts_ptr(h, b), 0, s);
     if (rc) return rc;
-    return launch_finish_loss(b->scalars, 1.0 / ((double)B * batch->io), s);
+    return launch_finish_loss(b->scalars, 1.0 / ((double)B * batch->io), s, loss_parts_ptr(h, b), mse_loss_colsum_rows(B));
 }
 
 int codae_eval_step(codae_handle h, const codae_buffers* b, const codae_batch* batch, float* out_y, void* stream) {

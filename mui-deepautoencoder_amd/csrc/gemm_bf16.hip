@@ -361,9 +361,8 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
         if (threadIdx.x == 0) {
             float a = 0.f, b2 = 0.f;
             for (int ww = 0; ww < NW; ++ww) { a += wsum[2 * ww]; b2 += wsum[2 * ww + 1]; }
-            atomicAdd(&L.scalars[CODAE_S_SQ_FULL], (double)a);
-            atomicAdd(&L.scalars[CODAE_S_STEP_SQ], (double)a);
-            if (masked) atomicAdd(&L.scalars[CODAE_S_SQ_PARTIAL], (double)b2);
+            L.parts[2 * bid] = (double)a;                       // (bid: tile index after the XCD remap, < gridDim.x)
+            L.parts[2 * bid + 1] = masked ? (double)b2 : 0.0;
         }
         if (g.colsum_part != nullptr) {
             for (int col = threadIdx.x; col < BN; col += NT) {
@@ -554,6 +553,12 @@ int gemm_bf16_colsum_rows(const GemmBf16& g) {
     return (g.M + bm - 1) / bm;
 }
 
+int gemm_bf16_loss_parts(const GemmBf16& g) {
+    const int t = gemm_bf16_tile_big(g.M, g.N, 1);
+    const int bm = t ? 256 : 128, bn = t ? 192 : 128;
+    return ((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
+}
+
 int gemm_bf16(const GemmBf16& g, hipStream_t s) {
     CODAE_REQUIRE(gemm_bf16_supported(g.M, g.N, g.K), "gemm_bf16: unsupported shape M=%d N=%d K=%d (need K %% 64 == 0, N %% 8 == 0)",
                   g.M, g.N, g.K);
@@ -569,7 +574,7 @@ int gemm_bf16(const GemmBf16& g, hipStream_t s) {
     if (g.loss.enabled) {
         CODAE_REQUIRE(g.a_mode == OP_KC && g.b_mode == OP_KC && !g.c_f32 && g.split_k == 1 && !g.relu && !g.relu_src,
                       "gemm_bf16: fused loss only on the plain forward form");
-        CODAE_REQUIRE(g.loss.data && g.loss.scalars && g.loss.io == g.N && g.loss.B <= g.M && (g.N % 8) == 0,
+        CODAE_REQUIRE(g.loss.data && g.loss.parts && g.loss.io == g.N && g.loss.B <= g.M && (g.N % 8) == 0,
                       "gemm_bf16: fused loss arguments");
         CODAE_REQUIRE(!(g.loss.mask_id || g.loss.mask_to_use) || ((reinterpret_cast<uintptr_t>(g.loss.table) & 7) == 0),
                       "gemm_bf16: mask table must be 8-byte aligned");

@@ -547,6 +547,7 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
             }
         };
         if (j0 + BN <= g.N) loss_rows(std::true_type{}); else loss_rows(std::false_type{});
+        stamp(3);                 // (DBG 8: loss arithmetic done, dy tile staged)
         phase_barrier();
         {
             constexpr int CH = BN / 8, RL = NT / CH;
@@ -562,7 +563,8 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
                 }
             }
         }
-        // metric sums: lanes -> wave -> workgroup -> one double atomic each (exact: the addends are fp32)
+        if constexpr (dbg_time) { wait_vmcnt<0>(); stamp(4); }
+        // metric sums: lanes -> wave -> workgroup -> this workgroup's row of L.parts
 #pragma unroll
         for (int o2 = 32; o2 > 0; o2 >>= 1) { sq += __shfl_xor(sq, o2); sqp += __shfl_xor(sqp, o2); }
         // column sums of dy (the last bias gradient): the 16 row-lanes of a column group, then the WM wave rows
@@ -595,9 +597,8 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
         if (threadIdx.x == 0) {
             float a = 0.f, b2 = 0.f;
             for (int ww = 0; ww < NW; ++ww) { a += wsum[2 * ww]; b2 += wsum[2 * ww + 1]; }
-            atomicAdd(&L.scalars[CODAE_S_SQ_FULL], (double)a);
-            atomicAdd(&L.scalars[CODAE_S_STEP_SQ], (double)a);
-            if (masked) atomicAdd(&L.scalars[CODAE_S_SQ_PARTIAL], (double)b2);
+            L.parts[2 * bid] = (double)a;                       // (bid: tile index after the XCD remap, < gridDim.x)
+            L.parts[2 * bid + 1] = masked ? (double)b2 : 0.0;
         }
         if (g.colsum_part != nullptr) {
             for (int col = threadIdx.x; col < BN; col += NT) {
@@ -778,7 +779,14 @@ int launch_dbg(const GemmBf16& g, hipStream_t s) {
 
 // cfg 0: 256 x 192 with 4 waves; cfg 1: 256 x 192 with 8 waves
 int gemm_bf16_pipe(const GemmBf16& g, int cfg, hipStream_t s) {
-    if (g.dbg && g.a_mode == OP_KC && g.b_mode == OP_KC && !g.c_f32 && g.split_k == 1) {
+    if (g.dbg == 8 && g.loss.enabled) {          // stamped build of the fused-loss kernel (tools/timeline_loss.py)
+        const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 191) / 192;
+        hipLaunchKernelGGL((gemm_bf16_pipe_kernel<256, 192, 4, 2, 6, OP_KC, OP_KC, false, 8, 3>), dim3(tiles_m * tiles_n), dim3(512), 0, s, g,
+                           tiles_n, tiles_m * tiles_n, g.K / BK);
+        CODAE_LAUNCH_CHECK();
+        return CODAE_OK;
+    }
+    if (g.dbg && !g.loss.enabled && g.a_mode == OP_KC && g.b_mode == OP_KC && !g.c_f32 && g.split_k == 1) {
         switch (g.dbg) {
             case 1: return launch_dbg<1>(g, s);
             case 2: return launch_dbg<2>(g, s);

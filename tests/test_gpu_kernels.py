@@ -211,6 +211,43 @@ def test_bf16_gemms_full_size_random(hip):
     assert np.allclose(f64(dW[cols]), ref, rtol=1e-3, atol=1e-5)
 
 
+def test_bf16_gemms_c5_size_random(hip):
+    """BASELINE config C5's GEMM shape (6 slots x 1024 = 6144 wide, batch 16384): the three forms on random data against
+    a float64 product of the bf16-rounded operands on sampled rows / columns (the full product is 1.2 TFLOP: too much
+    for the host), plus a size-independent property - linearity in the left operand."""
+    M, N, K = 16384, 6144, 6144
+    L = hip.lib()
+    g = torch.Generator(device="cpu").manual_seed(23)
+    x = torch.rand(M, K, generator=g).to(dev()).bfloat16()
+    W = ((torch.rand(N, K, generator=g) * 2 - 1) * 0.02).to(dev()).bfloat16()
+    b = torch.randn(N, generator=g).to(dev())
+    y = torch.empty(M, N, device=dev(), dtype=torch.bfloat16)
+    hip.check(L.codae_linear_bf16(hip.ptr(x), hip.ptr(W), hip.ptr(b), hip.ptr(y), 0, M, N, K, 1, hip.current_stream()))
+    sync()
+    rows = [0, 255, 256, 8191, 12345, 16383]
+    ref = np.maximum(f64(x[rows].float()) @ f64(W.float()).T + f64(b), 0)
+    assert np.allclose(f64(y[rows].float()), ref, rtol=1e-2, atol=2e-2)
+    # y(2x) - b = 2 (y(x) - b) exactly in bf16 x fp32-accumulate arithmetic (scaling by 2 is exact) where ReLU is off
+    y1 = torch.empty(M, N, device=dev(), dtype=torch.float32); y2 = torch.empty_like(y1)
+    x2 = (x.float() * 2).bfloat16()
+    hip.check(L.codae_linear_bf16(hip.ptr(x), hip.ptr(W), None, hip.ptr(y1), 1, M, N, K, 0, hip.current_stream()))
+    hip.check(L.codae_linear_bf16(hip.ptr(x2), hip.ptr(W), None, hip.ptr(y2), 1, M, N, K, 0, hip.current_stream()))
+    sync()
+    assert torch.equal(y2, 2 * y1)
+    del y1, y2, x2
+    dy = (torch.randn(M, N, generator=g) * 1e-3).to(dev()).bfloat16()
+    dx = torch.empty(M, K, device=dev(), dtype=torch.bfloat16)
+    hip.check(L.codae_dgrad_bf16(hip.ptr(dy), hip.ptr(W), None, hip.ptr(dx), None, None, M, N, K, hip.current_stream()))
+    dW = torch.empty(N, K, device=dev())
+    hip.check(L.codae_wgrad_bf16(hip.ptr(dy), hip.ptr(x), hip.ptr(dW), None, 0, M, N, K, hip.current_stream()))
+    sync()
+    ref = f64(dy[rows].float()) @ f64(W.float())
+    assert np.allclose(f64(dx[rows].float()), ref, rtol=1e-2, atol=1e-5)
+    cols = [0, 191, 192, 3071, 6143]
+    ref = f64(dy.float()[:, cols]).T @ f64(x.float())
+    assert np.allclose(f64(dW[cols]), ref, rtol=1e-3, atol=1e-5)
+
+
 # ---------------------------------------------------------------------------------------------
 # elementwise kernels vs the oracle
 # ---------------------------------------------------------------------------------------------

@@ -505,6 +505,57 @@ def test_full_size_c3_gradient_is_additive_over_row_shards():
     assert float((full[nw:] - halves[nw:]).abs().max()) <= 2e-3 * float(full[nw:].abs().max())
 
 
+def test_full_size_c5_step_properties():
+    """BASELINE config C5 (6 slots x 1024 = io 6144, 10 x Linear(6144,6144), batch 16384, bf16) through size-independent
+    properties: (1) the gradient of the full batch equals the sum of the gradients of its two halves when the loss is
+    scaled by the global batch (what the 8-GPU sharding of this config rests on); (2) the same inputs give the same
+    bits twice; (3) one optimizer step lowers the loss on the batch it was computed on; (4) the bf16 weight shadow and
+    its transposed copy, written by the Adam pass, are exactly the rounded fp32 parameters."""
+    from codae.hip.engine import DaeEngine
+    S, E, B, L = 6, 1024, 16384, 10
+    io = S * E
+    g = torch.Generator(device="cpu").manual_seed(31)
+    relu = [True] * 4 + [False] + [True] * 4 + [False]
+    eng = DaeEngine([(io, io, r) for r in relu], B, "bf16", DEV)
+    lim = (6.0 / (2 * io)) ** 0.5
+    eng.load_params([((torch.rand(io, io, generator=g) * 2 - 1) * lim, torch.zeros(io)) for _ in range(L)])
+    data = torch.rand(B + 64, io, generator=g).to(DEV)
+    table = torch.ones(S, io, dtype=torch.uint8)
+    for s in range(S):
+        table[s, s * E:(s + 1) * E] = 0
+    table = table.to(DEV)
+    mask_id = torch.randint(0, S, (B,), generator=g, dtype=torch.int32).to(DEV)
+    rows = torch.randperm(B + 64, generator=g)[:B].to(torch.int32).to(DEV)
+    hyper = eng.hyper(1e-4, 1e-4, clip=1.0, global_rows=B)
+
+    def grads_of(lo, hi):
+        batch = eng.make_batch(data, rows[lo:hi].contiguous(), mask_id[lo:hi].contiguous(), table)
+        eng.step_forward_loss(batch, hyper)
+        eng.step_backward(hi - lo, 0, L)
+        torch.cuda.synchronize()
+        return eng.grads.clone()
+
+    full = grads_of(0, B)
+    nw = eng.b_off[0]
+    assert float(full[:nw].abs().max()) > 0 and bool(torch.isfinite(full).all())
+    assert torch.equal(full, grads_of(0, B))
+    halves = grads_of(0, B // 2)
+    halves += grads_of(B // 2, B)
+    assert float((full[:nw] - halves[:nw]).abs().max()) <= 2e-3 * float(full[:nw].abs().max())
+    assert float((full[nw:] - halves[nw:]).abs().max()) <= 2e-3 * float(full[nw:].abs().max())
+    del halves
+    batch = eng.make_batch(data, rows, mask_id, table)
+    eng.train_step(batch, hyper)
+    l0 = eng.read_scalars()[3]
+    eng.train_step(batch, eng.hyper(1e-4, 1e-4, clip=1.0, global_rows=B))
+    l1 = eng.read_scalars()[3]
+    assert l1 < l0, (l0, l1)
+    w3 = eng.weight(3)
+    sh = eng.shadow[eng.w_off[3]:eng.w_off[3] + io * io].view(io, io)
+    sht = eng.shadow_t[eng.w_off[3]:eng.w_off[3] + io * io].view(io, io)
+    assert torch.equal(sh, w3.bfloat16()) and torch.equal(sht, w3.bfloat16().t())
+
+
 def test_step_is_bitwise_deterministic_run_to_run():
     """round 1's bias-gradient column sums used atomicAdd(float), so two runs of the product on the
     same inputs differed in the last bits.  Now every reduction has a fixed order: 5 unsynchronised steps, twice, from
