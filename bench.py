@@ -333,6 +333,20 @@ def main():
             # roofline is quoted on: its launches run alone on the chip.  The dgrad and wgrad launches of one
             # layer run CONCURRENTLY on two streams, so their per-launch event times overlap (by_kernel keeps them).
             dom = "gemm_fwd" if "gemm_fwd" in by else max(by, key=lambda k: by[k]["ms_per_step"])
+            if dom == "chain":
+                # narrow stack: the persistent fused chain is the step's dominant kernel.  Its arithmetic is tiny
+                # (forward + data gradients); what it has to MOVE through HBM per launch: the gathered batch (fp32), every
+                # layer's saved activation and activation gradient (bf16, written once), both weight shadows once.
+                rows = (B + 63) // 64 * 64
+                wbytes = sum(k * n for k, n, _ in schedule) * 2
+                abytes = sum(rows * k for k, _, _ in schedule) * 2 + sum(rows * n for _, n, _ in schedule) * 2
+                alg = B * io * 4 + abytes + 2 * wbytes
+                gbs = alg / (by[dom]["mean_ms"] * 1e-3) / 1e9
+                by[dom]["tflops"] = 2.0 * B * (2 * sum(k * n for k, n, _ in schedule) - schedule[0][0] * schedule[0][1]) / (by[dom]["mean_ms"] * 1e-3) / 1e12
+                roof = {"bound": "hbm", "kernel": dom, "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                        "traffic": None, "traffic_source": None, "bytes_per_launch": alg, "by_kernel": by,
+                        "note": "launch- and L2-latency-bound shape: every workgroup (16 batch rows) streams all weights "
+                                "from L2 once per direction; neither HBM nor MFMA is near its roofline at this size"}
             # HBM-side bytes per launch of the dominant kernel: an OFFLINE measurement (two rocprofv3 --pmc passes of this
             # very command, reduced by tools/hbm_traffic.py), keyed by workload + precision; null for any other shape
             traffic, traffic_src = None, None
@@ -348,9 +362,10 @@ def main():
                             wkey, rec.get("_source", "?"))
                 except Exception:
                     traffic = None
-            roof = {"bound": "mfma", "kernel": dom, "achieved": by[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
-                    "frac": by[dom]["tflops"] / peak, "traffic": traffic, "traffic_source": traffic_src,
-                    "flops_per_launch": gemm_flops, "by_kernel": by}
+            if roof is None:
+                roof = {"bound": "mfma", "kernel": dom, "achieved": by[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
+                        "frac": by[dom]["tflops"] / peak, "traffic": traffic, "traffic_source": traffic_src,
+                        "flops_per_launch": gemm_flops, "by_kernel": by}
         out["roofline"] = roof
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(schedule, data, blank, io, slots, B)

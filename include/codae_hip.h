@@ -211,7 +211,12 @@ int codae_side_stream(codae_handle h, void** stream_out);
  * slab reduces of a backward issued with codae_step_backward_async).  Call before anything on `stream`, another
  * stream or the host reads the weight gradients; codae_step_update does so itself. */
 int codae_join(codae_handle h, void* stream);
-/* all three, single GPU */
+/* all three, single GPU.  Narrow stacks (bf16, every width <= 512, at most 15 layers, batch <= 8192 rows) take the
+ * persistent fused chain instead of per-layer launches: ONE kernel for gather + corruption + all forward layers +
+ * loss + the whole data-gradient chain (a workgroup walks 16 batch rows through every layer; weights stream from
+ * L2), ONE grouped launch for every layer's weight gradient, then bias finish, loss finish, norm, Adam: 6 launches
+ * instead of ~55 (the reference's stock BATCH_SIZE 128 and BASELINE config 2 are launch-bound).  Same arithmetic, same
+ * buffers; CODAE_NO_CHAIN=1 keeps the per-layer path. */
 int codae_train_step(codae_handle h, const codae_buffers* bufs, const codae_batch* batch,
                      const codae_hyper* hyper, void* stream);
 /* validation body (:245-258): forward + metric sums only */
@@ -229,7 +234,9 @@ enum {
     CODAE_K_SUMSQ = 5,
     CODAE_K_ADAM = 6,
     CODAE_K_SLAB_REDUCE = 7,
-    CODAE_K_COUNT = 8
+    CODAE_K_CHAIN = 8,       /* narrow stacks: gather + forward chain + loss + data-gradient chain in one launch */
+    CODAE_K_BIAS_FINISH = 9, /* partial column sums -> bias gradients (+ their share of sum g^2) */
+    CODAE_K_COUNT = 10
 };
 /* Start recording a hipEvent pair around every launch whose class bit is set in class_mask
  * (bit k = CODAE_K_k), on the stream the launch uses; at most max_records pairs are kept. */

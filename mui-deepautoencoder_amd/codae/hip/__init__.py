@@ -18,7 +18,8 @@ ABI_VERSION = 3
 # CODAE_S_* of include/codae_hip.h (tests/test_host_logic.py parses the header and compares)
 S_SQ_FULL, S_SQ_PARTIAL, S_GRAD_SQ, S_LAST_LOSS, S_STEP_SQ, S_CLIP_COEF = 0, 1, 2, 3, 4, 5
 S_GRAD_SQ_SLOTS, S_N_SLOTS, S_ADAM_STEP, S_COUNT = 8, 64, 72, 80
-KERNEL_CLASSES = ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "loss", "gather", "sumsq", "adam", "slab_reduce")
+KERNEL_CLASSES = ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "loss", "gather", "sumsq", "adam", "slab_reduce", "chain",
+                  "bias_finish")
 
 
 class HipError(RuntimeError):

@@ -151,6 +151,39 @@ int gemm_bf16_loss_parts(const GemmBf16& g);    // workgroups of the fused-loss 
 int gemm_bf16(const GemmBf16& g, hipStream_t s);
 int gemm_bf16_pipe(const GemmBf16& g, int cfg, hipStream_t s);   // gemm_bf16_pipe.hip
 
+// several independent GEMMs (here: the weight gradients of every layer of a narrow stack) in ONE launch; tile
+// configuration 128 x 128 for all of them
+constexpr int CODAE_GROUP_MAX = 16;
+struct GemmBf16Group {
+    int n;
+    GemmBf16 g[CODAE_GROUP_MAX];
+    int wg_begin[CODAE_GROUP_MAX + 1];     // prefix sum of workgroups per GEMM (filled by the launcher)
+};
+int gemm_bf16_grouped(GemmBf16Group& grp, hipStream_t s);
+
+// ---- persistent fused chain for narrow stacks (chain_bf16.hip) ----------------
+constexpr int CODAE_CHAIN_MAX_WIDTH = 512;
+constexpr int CODAE_CHAIN_MAX_LAYERS = 16;
+struct ChainArgs {
+    int L, rows, B;                                  // rows: batch padded to a multiple of 64
+    int width[CODAE_CHAIN_MAX_LAYERS + 1];           // width[l] = input of layer l, width[L] = output of the last
+    uint8_t relu[CODAE_CHAIN_MAX_LAYERS];
+    const bf16_t* W[CODAE_CHAIN_MAX_LAYERS];         // bf16 weight shadow   [out][in]
+    const bf16_t* Wt[CODAE_CHAIN_MAX_LAYERS];        // transposed shadow    [in][out]
+    const float* bias[CODAE_CHAIN_MAX_LAYERS];
+    bf16_t* act[CODAE_CHAIN_MAX_LAYERS];             // act[l] [rows][width[l]]: input of layer l (saved for the backward)
+    bf16_t* dact[CODAE_CHAIN_MAX_LAYERS];            // dact[l] [rows][width[l+1]]: gradient of layer l's output
+    float* colsum_part[CODAE_CHAIN_MAX_LAYERS];      // [rows / 16][width[l+1]] partial bias gradients
+    const float* data; const int32_t* row_idx; const int32_t* mask_id; const uint8_t* mask_table;
+    const int32_t* mask_to_use; int nb_run, run;
+    float inv_n;                                     // 1 / (global rows * io)
+    double* loss_parts;                              // [rows / 16][2]
+    int do_backward;
+};
+bool chain_supported(int L, const int* in, const int* out);
+int chain_rows_per_workgroup();
+int launch_chain_step(const ChainArgs& a, hipStream_t s);
+
 // ---- elementwise / reductions (elementwise.hip) ----------------------------
 int launch_gather_corrupt(const codae_batch* b, void* out, int out_bf16, hipStream_t s);
 int launch_cast_bf16(const float* src, bf16_t* dst, int64_t n, hipStream_t s);

@@ -449,7 +449,15 @@ __global__ __launch_bounds__(NT) void bias_finish_kernel(BiasFinishJobs jobs, do
         const int N = jobs.cols[j], R = jobs.rows[j];
         const float* p = jobs.parts[j] + c;
         float s = 0.f;
-        for (int r = 0; r < R; ++r) s += p[(int64_t)r * N];
+        int r = 0;
+        for (; r + 8 <= R; r += 8) {                // 8 independent loads in flight, added in row order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(r + u) * N];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; r < R; ++r) s += p[(int64_t)r * N];
         jobs.out[j][c] = s;
         sq = s * s;
     }

@@ -77,6 +77,7 @@ struct codae_engine {
     int64_t part_floats = 0;
     int64_t loss_part_off = 0;       // (floats, 8-byte aligned) per-workgroup metric sums of the loss kernels
     int loss_part_cap = 0;
+    bool chain_ok = false;           // narrow bf16 stack: codae_train_step may take the persistent fused chain
     mutable std::vector<int> parts_pending;
     // optional per-launch hipEvent pairs (codae_profile_begin / _end)
     // backward on two streams: the weight-gradient GEMMs (+ slab reduce) run on `side`, concurrently with
@@ -221,7 +222,70 @@ int finish_bias(const codae_engine* e, const codae_buffers* b, hipStream_t s, bo
     }
     if (jobs.n == 0) return CODAE_OK;
     jobs.col_begin[jobs.n] = cols;
+    ProfScope prof(e, CODAE_K_BIAS_FINISH, s);
     return launch_bias_finish(jobs, with_norm ? b->scalars + CODAE_S_GRAD_SQ : nullptr, s);
+}
+
+constexpr int CHAIN_MAX_ROWS = 8192;      // beyond this the per-layer GEMMs (weights read once per 256 rows) win
+
+bool chain_eligible(const codae_engine* e, const codae_buffers* b, int B) {
+    return e->chain_ok && b->shadow_wt != nullptr && e->rows_for(B) <= CHAIN_MAX_ROWS;
+}
+
+// gather + forward chain + loss (+ data-gradient chain) of a narrow stack: one launch; then the loss finish
+int run_chain(const codae_engine* e, const codae_buffers* b, const codae_batch* batch, const codae_hyper* hyper, bool backward,
+              hipStream_t s) {
+    const int B = batch->B, L = e->L, rows = e->rows_for(B);
+    ChainArgs a{};
+    a.L = L; a.rows = rows; a.B = B;
+    for (int l = 0; l < L; ++l) {
+        a.width[l] = e->in[l];
+        a.relu[l] = e->relu[l];
+        a.W[l] = reinterpret_cast<const bf16_t*>(b->shadow_w) + e->w_off[l];
+        a.Wt[l] = reinterpret_cast<const bf16_t*>(b->shadow_wt) + e->w_off[l];
+        a.bias[l] = b->params + e->b_off[l];
+        a.act[l] = reinterpret_cast<bf16_t*>(act_ptr(e, b, l));
+        a.dact[l] = reinterpret_cast<bf16_t*>(dact_ptr(e, b, l));
+        a.colsum_part[l] = part_ptr(e, b, l);
+    }
+    a.width[L] = e->out[L - 1];
+    a.data = batch->data; a.row_idx = batch->row_idx; a.mask_id = batch->mask_id; a.mask_table = batch->mask_table;
+    a.mask_to_use = batch->mask_to_use; a.nb_run = batch->nb_run; a.run = batch->run;
+    const double n_glob = (double)(hyper != nullptr && hyper->loss_scale_rows > 0.f ? hyper->loss_scale_rows : (float)B) * batch->io;
+    a.inv_n = (float)(1.0 / n_glob);
+    a.loss_parts = loss_parts_ptr(e, b);
+    a.do_backward = backward ? 1 : 0;
+    const int n_wg = rows / chain_rows_per_workgroup();
+    CODAE_REQUIRE(n_wg <= e->loss_part_cap, "chain: %d workgroups exceed the partial-sum rows (%d)", n_wg, e->loss_part_cap);
+    int rc;
+    {
+        ProfScope prof(e, CODAE_K_CHAIN, s);
+        rc = launch_chain_step(a, s);
+    }
+    if (rc) return rc;
+    if (backward)
+        for (int l = 0; l < L; ++l) e->parts_pending[l] = n_wg;
+    e->norm_scalars_zero = true;
+    return launch_finish_loss(b->scalars, 1.0 / ((double)B * batch->io), s, loss_parts_ptr(e, b), n_wg);
+}
+
+// every layer's weight gradient dW_l = dA_l^T H_l in one grouped launch (fp32 straight into grads: no split-K slabs)
+int run_wgrad_grouped(const codae_engine* e, const codae_buffers* b, int rows, hipStream_t s) {
+    for (int base = 0; base < e->L; base += CODAE_GROUP_MAX) {
+        GemmBf16Group grp{};
+        grp.n = 0;
+        for (int l = base; l < e->L && grp.n < CODAE_GROUP_MAX; ++l) {
+            GemmBf16& g = grp.g[grp.n++];
+            g.A = reinterpret_cast<const bf16_t*>(dact_ptr(e, b, l)); g.lda = e->out[l]; g.a_mode = OP_KS;
+            g.B = reinterpret_cast<const bf16_t*>(act_ptr(e, b, l)); g.ldb = e->in[l]; g.b_mode = OP_KS;
+            g.C = b->grads + e->w_off[l]; g.ldc = e->in[l]; g.c_f32 = 1;
+            g.M = e->out[l]; g.N = e->in[l]; g.K = rows; g.split_k = 1;
+        }
+        ProfScope prof(e, CODAE_K_GEMM_WGRAD, s);
+        int rc = gemm_bf16_grouped(grp, s);
+        if (rc) return rc;
+    }
+    return CODAE_OK;
 }
 
 // y = act(x W^T + b) for layer l
@@ -523,13 +587,17 @@ int codae_create(const codae_spec* spec, codae_handle* out) {
     // two backward streams, whose barrier packets cost ~11 us each); deeper stacks rotate through CODAE_MAX_DACT
     e->n_dact = e->L + 1 <= CODAE_MAX_DACT ? e->L + 1 : CODAE_MAX_DACT;
     if (e->n_dact < 3) e->n_dact = 3;
+    e->chain_ok = e->prec == CODAE_PREC_BF16 && !e->cfg.no_chain && e->L + 1 <= CODAE_MAX_DACT &&
+                  chain_supported(e->L, e->in.data(), e->out.data()) && e->in[0] == e->out[e->L - 1];
     // partial column-sum rows per layer: a producer writes at most one row per 64 batch rows (exact-fp32 GEMM, dense
-    // colsum), the stand-alone loss kernel of the last layer one per 32
+    // colsum), the stand-alone loss kernel of the last layer one per 32, the persistent chain one per 16
     e->parts_pending.assign(e->L, 0);
     e->part_floats = 0;
+    const int chain_rows = e->max_rows < CHAIN_MAX_ROWS ? e->max_rows : CHAIN_MAX_ROWS;
     for (int l = 0; l < e->L; ++l) {
         e->part_off.push_back(e->part_floats);
-        const int64_t rows_cap = (l == e->L - 1) ? (e->max_rows + 31) / 32 : (e->max_rows + 63) / 64;
+        int64_t rows_cap = (l == e->L - 1) ? (e->max_rows + 31) / 32 : (e->max_rows + 63) / 64;
+        if (e->chain_ok && chain_rows / 16 > rows_cap) rows_cap = chain_rows / 16;
         e->part_floats += round_up(rows_cap * (int64_t)e->out[l], 64);
     }
     {   // + the loss kernels' per-workgroup metric sums: [workgroups][2] doubles
@@ -537,6 +605,7 @@ int codae_create(const codae_spec* spec, codae_handle* out) {
         const int by_rows = (e->max_rows + 31) / 32;                                             // stand-alone loss kernel
         const int by_tiles = ((e->max_rows + 127) / 128) * ((io + 127) / 128);                   // fused into the last GEMM
         e->loss_part_cap = by_rows > by_tiles ? by_rows : by_tiles;
+        if (e->chain_ok && chain_rows / 16 > e->loss_part_cap) e->loss_part_cap = chain_rows / 16;
         e->loss_part_off = e->part_floats;
         e->part_floats += round_up((int64_t)e->loss_part_cap * 4, 64);
     }
@@ -850,6 +919,28 @@ int codae_join(codae_handle h, void* stream) {
 
 int codae_train_step(codae_handle h, const codae_buffers* b, const codae_batch* batch, const codae_hyper* hyper, void* stream) {
     CODAE_REQUIRE(hyper != nullptr, "codae_train_step: null hyper");
+    CODAE_REQUIRE(batch != nullptr, "codae_train_step: null batch");
+    if (h != nullptr && b != nullptr && chain_eligible(h, b, batch->B)) {
+        // narrow stack: persistent fused chain + grouped weight gradients (6 launches for the whole step)
+        int rcc = check_common(h, b, batch->B);
+        if (rcc) return rcc;
+        CODAE_REQUIRE(batch->io == h->in[0], "batch.io %d does not match the model (%d)", batch->io, h->in[0]);
+        CODAE_REQUIRE(b->grads && b->dacts && b->scalars && b->bias_parts, "codae_train_step: grads / dacts / scalars / bias_parts missing");
+        CODAE_REQUIRE(batch->data && batch->B > 0 && (!(batch->mask_id || batch->mask_to_use) || batch->mask_table), "codae_train_step: bad batch");
+        CODAE_REQUIRE(!batch->mask_to_use || batch->mask_id || (batch->nb_run > 0 && batch->run >= 0 && batch->run < batch->nb_run),
+                      "codae_train_step: run %d outside [0, %d)", batch->run, batch->nb_run);
+        if (h->prof_on) ++h->prof_step;
+        hipStream_t s = (hipStream_t)stream;
+        rcc = join_side(h, s);
+        if (rcc) return rcc;
+        rcc = run_chain(h, b, batch, hyper, true, s);
+        if (rcc) return rcc;
+        rcc = run_wgrad_grouped(h, b, h->rows_for(batch->B), s);
+        if (rcc) return rcc;
+        rcc = finish_bias(h, b, s, false);
+        if (rcc) return rcc;
+        return update_impl(h, b, hyper, s, false);
+    }
     int rc = codae_step_forward_loss(h, b, batch, hyper, nullptr, stream);
     if (rc) return rc;
     // single GPU: nothing happens to the gradients between backward and update, so the norm can be

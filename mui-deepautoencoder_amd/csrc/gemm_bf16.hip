@@ -145,15 +145,14 @@ __device__ __forceinline__ bf16x8 read_frag(const lds_char* tile, int t, int s, 
 }
 
 // Tile BM x BN x 64, WM x WN waves, each wave (BM/WM) x (BN/WN) = TM x TN MFMA tiles of 16 x 16.
-template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, bool C_F32, bool LOSS = false>
-__global__ __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256 * ((2 * (BM + BN) * 128 <= 80 * 1024) ? 2 : 1))
-void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
+// One output tile of one GEMM: the whole kernel body, so that the plain kernel (one GEMM per launch) and the grouped
+// kernel (several GEMMs per launch) share it.  wg / nwg: this workgroup's index among the nwg workgroups of ITS GEMM.
+template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, bool C_F32, bool LOSS>
+__device__ __forceinline__ void gemm_bf16_tile(const GemmBf16& g, int tiles_n, int tiles_mn, int kt_total, int wg, int nwg,
+                                               char* smem_raw) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
-    // LOSS: + {dataset row, mask id} of the tile's rows, fetched once at entry (two dependent loads that
-    // would otherwise sit in front of every row of the epilogue)
-    __shared__ __attribute__((aligned(16))) char smem_raw[2 * BUF_BYTES + (LOSS ? BM * 8 : 0)];
     lds_char* smem = (lds_char*)smem_raw;
 
     const int lane = threadIdx.x & 63;
@@ -161,8 +160,7 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
     const int wr = w / WN, wc = w % WN;
 
     // XCD-aware remap: consecutive tile ids (same A row panel) run on one XCD's L2
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
+    int bid = wg;
     {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -496,6 +494,27 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
     }
 }
 
+template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, bool C_F32, bool LOSS = false>
+__global__ __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256 * ((2 * (BM + BN) * 128 <= 80 * 1024) ? 2 : 1))
+void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
+    // LOSS: + {dataset row, mask id} of the tile's rows, fetched once at entry (two dependent loads that
+    // would otherwise sit in front of every row of the epilogue)
+    __shared__ __attribute__((aligned(16))) char smem_raw[2 * (BM + BN) * 128 + (LOSS ? BM * 8 : 0)];
+    gemm_bf16_tile<BM, BN, WM, WN, A_MODE, B_MODE, C_F32, LOSS>(g, tiles_n, tiles_mn, kt_total, blockIdx.x, gridDim.x, smem_raw);
+}
+
+// Several weight-gradient GEMMs (k-strided operands, fp32 output) in one launch: workgroup -> (GEMM, tile) by the prefix
+// sums in the descriptor block.  128 x 128 tiles: the narrow stacks this exists for have 9-16 tiles per layer.
+__global__ __launch_bounds__(256, 2) void gemm_bf16_grouped_kernel(GemmBf16Group grp) {
+    __shared__ __attribute__((aligned(16))) char smem_raw[2 * (128 + 128) * 128];
+    int j = 0;
+    while (j + 1 < grp.n && (int)blockIdx.x >= grp.wg_begin[j + 1]) ++j;
+    const GemmBf16& g = grp.g[j];
+    const int tiles_m = (g.M + 127) / 128, tiles_n = (g.N + 127) / 128;
+    gemm_bf16_tile<128, 128, 2, 2, OP_KS, OP_KS, true, false>(g, tiles_n, tiles_m * tiles_n, g.K / BK, blockIdx.x - grp.wg_begin[j],
+                                                              grp.wg_begin[j + 1] - grp.wg_begin[j], smem_raw);
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(const GemmBf16& g, hipStream_t s) {
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
@@ -522,6 +541,24 @@ int launch_cfg(const GemmBf16& g, hipStream_t s) {
 }
 
 }  // namespace
+
+int gemm_bf16_grouped(GemmBf16Group& grp, hipStream_t s) {
+    CODAE_REQUIRE(grp.n >= 1 && grp.n <= CODAE_GROUP_MAX, "gemm_bf16_grouped: %d GEMMs", grp.n);
+    int total = 0;
+    for (int j = 0; j < grp.n; ++j) {
+        const GemmBf16& g = grp.g[j];
+        CODAE_REQUIRE(g.a_mode == OP_KS && g.b_mode == OP_KS && g.c_f32 && g.split_k >= 1 && g.K % BK == 0 && g.K >= BK && g.M % 8 == 0 &&
+                          g.N % 8 == 0 && !g.loss.enabled && g.relu_src == nullptr && g.colsum_part == nullptr && g.bias == nullptr,
+                      "gemm_bf16_grouped: GEMM %d is not a plain weight-gradient form", j);
+        CODAE_REQUIRE(g.split_k <= g.K / BK, "gemm_bf16_grouped: split_k %d > k tiles", g.split_k);
+        grp.wg_begin[j] = total;
+        total += ((g.M + 127) / 128) * ((g.N + 127) / 128) * g.split_k;
+    }
+    grp.wg_begin[grp.n] = total;
+    hipLaunchKernelGGL(gemm_bf16_grouped_kernel, dim3(total), dim3(256), 0, s, grp);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
 
 bool gemm_bf16_supported(int M, int N, int K) {
     // K: whole BK tiles; N: 16-byte rows for vector epilogue / staged chunks

@@ -533,7 +533,7 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
                                 const float se = d * d;
                                 sq += se;
                                 sqp += ((mk[mt][nh][nt] >> (8 * k)) & 0xffu) == 0 ? se : 0.f;
-                                gq[k] = -2.f * d * L.inv_n;
+                                gq[k] = on ? -2.f * d * L.inv_n : 0.f;       // (+0 in pad rows / columns)
                                 cs[nh][nt][k] += gq[k];
                             }
                             u32x2 o;

@@ -20,6 +20,19 @@ torch = pytest.importorskip("torch")
 DEV = "cuda:0"
 
 
+@pytest.fixture(params=["chain", "layers"])
+def step_path(request, monkeypatch):
+    """Narrow bf16 stacks (every width <= 512) have two implementations of codae_train_step: the persistent fused chain
+    (one launch for gather + forward + loss + data gradients, one grouped launch for the weight gradients) and the
+    per-layer GEMM launches that wide stacks always take (CODAE_NO_CHAIN=1, read at codae_create).  Tests that use this
+    fixture run on both."""
+    if request.param == "layers":
+        monkeypatch.setenv("CODAE_NO_CHAIN", "1")
+    else:
+        monkeypatch.delenv("CODAE_NO_CHAIN", raising=False)
+    return request.param
+
+
 class FusedTrainerAdapter:
     """step/evaluate interface of tests/replay.py on top of HipEmbeddingTrainer."""
 
@@ -137,7 +150,7 @@ def bf16_replay_deviations(name):
 
 
 @pytest.mark.parametrize("name", ["embedding_wide_square", "embedding_wide_taper"])
-def test_fused_bf16_replays_reference_run(name):
+def test_fused_bf16_replays_reference_run(name, step_path):
     """The BENCHMARKED mode pinned to the reference: a whole run of the reference's own script (4 epochs, 36 optimizer
     steps + validation, widths multiples of 64) replayed through the bf16 engine; the loss curve is asserted per step."""
     d = bf16_replay_deviations(name)
@@ -152,7 +165,7 @@ def test_fused_bf16_replays_reference_run(name):
 
 
 @pytest.mark.parametrize("name", ["embedding_wide_square", "embedding_wide_taper"])
-def test_fused_bf16_matches_bf16_rounded_oracle(name):
+def test_fused_bf16_matches_bf16_rounded_oracle(name, step_path):
     """Pins the bf16 KERNELS (as opposed to the bf16 arithmetic): the oracle with its rounding hook restates the
     reference's algorithm with bf16 stores at the points where the engine rounds (input, weight shadow, activations,
     activation gradients; fp32 accumulation, fp32 master weights and Adam).  On the first step - identical parameters
@@ -353,7 +366,50 @@ def test_fused_f32_vs_oracle_3x128_batch1024():
         assert close(tr.engine.bias(l).cpu().numpy(), b)
 
 
-def test_fused_bf16_vs_oracle_3x128_batch1024():
+def test_chain_step_equals_per_layer_step(monkeypatch):
+    """The persistent fused chain against the per-layer launches on BASELINE config C2's shape (3 x 128, batch 1024; and a
+    ragged batch of a tapered stack): both run the same MFMA instruction over the same k order, so every saved
+    activation and every activation gradient must agree BIT FOR BIT (the whole workspaces are compared); weight
+    gradients differ only by fp32 summation order (the per-layer path splits the batch reduction 8 ways, the grouped
+    launch does not), bias gradients and the loss by how many rows a partial sum spans (16 vs 128)."""
+    from codae.hip.engine import DaeEngine
+    from oracle import dae_oracle as O
+    for (S, E, z, nl, B) in ((3, 128, 384, 4, 1024), (3, 64, 64, 2, 333)):
+        io = S * E
+        rng = np.random.default_rng(B)
+        sched = O.layer_schedule(io, z, nl, nl, False, "embedding")
+        params = O.init_params(sched, rng)
+        data = torch.tensor(rng.random((B + 50, io), dtype=np.float32), device=DEV)
+        bm, _, _ = O.corrupter_tables([{"size": E, "position": s * E} for s in range(S)], 1)
+        table = torch.tensor(bm).to(torch.uint8).to(DEV)
+        mid = torch.tensor(rng.integers(0, S, B), dtype=torch.int32, device=DEV)
+        rows = torch.tensor(rng.permutation(B + 50)[:B], dtype=torch.int32, device=DEV)
+        out = []
+        for chain in (True, False):
+            if chain:
+                monkeypatch.delenv("CODAE_NO_CHAIN", raising=False)
+            else:
+                monkeypatch.setenv("CODAE_NO_CHAIN", "1")
+            eng = DaeEngine(sched, B, "bf16", DEV)
+            eng.load_params(params)
+            batch = eng.make_batch(data, rows, mid, table)
+            eng.train_step(batch, eng.hyper(1e-3, 1e-4, clip=1.0, global_rows=B))
+            torch.cuda.synchronize()
+            out.append((eng.grads.clone(), eng.read_scalars(), eng.params.clone(), eng.b_off[0], eng.acts.clone(), eng.dacts.clone()))
+        (ga, sa, pa, nw, aa, da), (gb, sb, pb, _, ab, db) = out
+        assert torch.equal(aa, ab), "saved activations"
+        assert torch.equal(da, db), "activation gradients"
+        assert float(da.float().abs().max()) > 0
+        assert float((ga[:nw] - gb[:nw]).abs().max()) <= 1e-5 * float(gb[:nw].abs().max())
+        assert float((ga[nw:] - gb[nw:]).abs().max()) <= 1e-5 * float(gb[nw:].abs().max())
+        for k in (0, 1, 3):
+            assert abs(sa[k] - sb[k]) <= 1e-6 * abs(sb[k]), (k, sa, sb)
+        assert abs(sa[2] - sb[2]) <= 1e-5 * sb[2]
+        assert float((pa - pb).abs().max()) <= 2.1e-3          # (an Adam step moves an element by at most ~lr either way)
+        assert float((pa - pb).abs().mean()) <= 1e-6
+
+
+def test_fused_bf16_vs_oracle_3x128_batch1024(step_path):
     """bf16 operands, fp32 accumulate: loss / grad-norm within 2 % of the fp32 oracle (stated
     tolerance of the throughput mode); parameters move by lr-sized Adam steps either way."""
     tr, orc = _oracle_vs_engine("bf16", 3, 128, 1024, 3, 2e-2)
@@ -367,7 +423,7 @@ def test_fused_bf16_vs_oracle_3x128_batch1024():
         assert (d > lr).mean() < 0.02, (l, (d > lr).mean())
 
 
-def test_fused_bf16_ragged_batch():
+def test_fused_bf16_ragged_batch(step_path):
     """partial last batch (B not a multiple of 64): zero-padded rows must not leak into gradients."""
     tr, orc = _oracle_vs_engine("bf16", 3, 64, 200, 2, 2e-2)
 
@@ -391,6 +447,7 @@ def test_bucketed_allreduce_path_on_rccl_single_rank(monkeypatch):
     from codae.train import HipEmbeddingTrainer
     from oracle import dae_oracle as O
     monkeypatch.setenv("CODAE_DP_FORCE_ALLREDUCE", "1")
+    monkeypatch.setenv("CODAE_NO_CHAIN", "1")        # (the bucketed step is per-layer: compare it with the per-layer fused step)
     monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
     monkeypatch.setenv("MASTER_PORT", "29533")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
@@ -667,7 +724,7 @@ def _fuzz_cases():
 
 
 @pytest.mark.parametrize("S,E,z,nb_in,nb_out,B", _fuzz_cases())
-def test_fused_random_topologies_vs_oracle(S, E, z, nb_in, nb_out, B):
+def test_fused_random_topologies_vs_oracle(S, E, z, nb_in, nb_out, B, step_path):
     """Seeded random stacks (tapers to z, 2-4 hidden layers per side, ragged batches, every tile / split-K choice
     the dispatcher makes for them): two fused steps against the fp32 oracle - bf16 kernels when every width is a multiple
     of 64 (loss within 2 %, grad-norm 10 %), exact-fp32 kernels otherwise (1e-3 / 5e-3)."""
