@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not record per-launch hipEvents in the timed region (roofline then null)")
     ap.add_argument("--buckets", type=int, default=4)
+    ap.add_argument("--sharded-update", action="store_true",
+                    help="N > 1: reduce-scatter the gradient buckets, Adam on 1/N of the parameters, all-gather the bf16 shadows")
     ap.add_argument("--fwd-events-only", action="store_true", help="time only the forward GEMM class")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (single GPU; no live kernel events)")
     args = ap.parse_args()
@@ -211,7 +213,8 @@ def main():
 
     tr = HipEmbeddingTrainer(schedule, torch.from_numpy(data), torch.from_numpy(table), mask_to_use, LR, WD, CLIP,
                              max_batch=B, precision=args.precision, device=dev, distributed=distributed,
-                             n_buckets=args.buckets, use_graph=args.graph and not distributed)
+                             n_buckets=args.buckets, use_graph=args.graph and not distributed,
+                             sharded_update=args.sharded_update)
     tr.init_params(seed=0)
 
     # per-step row indices, resident before timing: one permutation of the dataset per epoch, the
@@ -265,7 +268,8 @@ def main():
     dp_info = None
     if distributed:
         dp_info = {"rccl_ranks": int(dist.get_world_size()), "backend": dist.get_backend(),
-                   "buckets": [list(b) for b in tr.dp.buckets], "exposed_wait_ms_per_step": tr.dp.wait_report()}
+                   "buckets": [list(b) for b in tr.dp.buckets], "exposed_wait_ms_per_step": tr.dp.wait_report(),
+                   "sharded_update": bool(tr.dp.sharded)}
 
     # exact-fp32 (parity) mode on the same workload: the mode every reference-pinned rtol 1e-3 / atol 1e-5 replay runs in
     f32_parity = None

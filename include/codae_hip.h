@@ -211,6 +211,20 @@ int codae_side_stream(codae_handle h, void** stream_out);
  * slab reduces of a backward issued with codae_step_backward_async).  Call before anything on `stream`, another
  * stream or the host reads the weight gradients; codae_step_update does so itself. */
 int codae_join(codae_handle h, void* stream);
+
+/* ---- sharded data-parallel update (reduce-scatter -> Adam on 1/N of the parameters -> all-gather of the bf16 shadows)
+ * What torch's ZeroRedundancyOptimizer would do around optimizer.step() (script/train_dae_on_embedding.py:212-215): each
+ * rank owns a contiguous shard of every gradient bucket.  The caller (codae.train.DataParallel(sharded=True)) runs the
+ * collectives; these three entry points are the arithmetic in between. */
+/* *acc (device double) += sum g[i]^2, i in [0, n): a rank's share of clip_grad_norm_'s total norm */
+int codae_span_sumsq(const float* g, int64_t n, double* acc, void* stream);
+/* clip + Adam on elements [lo, hi) of the flat parameter / gradient / moment vectors, *total_sq (device double) being
+ * the GLOBAL sum g^2 (all-reduced over the ranks); writes the bf16 shadow of the range (BF16 mode).  lo, hi multiples
+ * of 4.  Does not touch the transposed shadow: codae_sync_transposed after the shadows have been all-gathered. */
+int codae_step_update_span(codae_handle h, const codae_buffers* bufs, const codae_hyper* hyper, int64_t lo, int64_t hi,
+                           const double* total_sq, void* stream);
+/* shadow_wt <- transpose(shadow_w) for every layer that has a data gradient (BF16 mode; no-op otherwise) */
+int codae_sync_transposed(codae_handle h, const codae_buffers* bufs, void* stream);
 /* all three, single GPU.  Narrow stacks (bf16, every width <= 512, at most 15 layers, batch <= 8192 rows) take the
  * persistent fused chain instead of per-layer launches: ONE kernel for gather + corruption + all forward layers +
  * loss + the whole data-gradient chain (a workgroup walks 16 batch rows through every layer; weights stream from

@@ -82,6 +82,9 @@ PROTOTYPES = {
     "codae_side_stream": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
     "codae_profile_stride": (C.c_int, [_P, _I32]),
     "codae_join": (C.c_int, [_P, _P]),
+    "codae_span_sumsq": (C.c_int, [_P, _I64, _P, _P]),
+    "codae_step_update_span": (C.c_int, [_P, C.POINTER(Buffers), C.POINTER(Hyper), _I64, _I64, _P, _P]),
+    "codae_sync_transposed": (C.c_int, [_P, C.POINTER(Buffers), _P]),
     "codae_train_step": (C.c_int, [_P, C.POINTER(Buffers), C.POINTER(Batch), C.POINTER(Hyper), _P]),
     "codae_train_step_graph": (C.c_int, [_P, C.POINTER(Buffers), C.POINTER(Batch), C.POINTER(Hyper), _P]),
     "codae_eval_step": (C.c_int, [_P, C.POINTER(Buffers), C.POINTER(Batch), _P, _P]),

@@ -215,6 +215,31 @@ class DaeEngine:
             check(self._lib.codae_step_update(self._h, C.byref(self.bufs), C.byref(hyper), current_stream()))
         self.step_count += 1
 
+    # ---- sharded data-parallel update (codae.train.DataParallel(sharded=True)) -------------------
+    def span_sumsq(self, lo, hi, acc):
+        """acc (1-element float64 device tensor) += sum grads[lo:hi]^2."""
+        with torch.cuda.device(self.device):
+            check(self._lib.codae_span_sumsq(C.c_void_p(self.grads.data_ptr() + 4 * lo), hi - lo, ptr(acc), current_stream()))
+
+    def step_update_span(self, hyper, lo, hi, total_sq):
+        """clip + Adam on flat elements [lo, hi) with the global sum g^2 in `total_sq` (float64 device tensor)."""
+        with torch.cuda.device(self.device):
+            check(self._lib.codae_step_update_span(self._h, C.byref(self.bufs), C.byref(hyper), lo, hi, ptr(total_sq),
+                                                   current_stream()))
+
+    def replica_tensors(self):
+        """Flat tensors (parameter layout) every rank must hold in full for the next forward / backward: the bf16 weight
+        shadow in BF16 mode (biases are updated on every rank), the fp32 parameters in F32 mode."""
+        return [self.shadow] if self.precision == PREC_BF16 else [self._params]
+
+    def after_replica_sync(self):
+        """The shadows were all-gathered: rebuild the transposed copies the data-gradient GEMMs read."""
+        with torch.cuda.device(self.device):
+            check(self._lib.codae_sync_transposed(self._h, C.byref(self.bufs), current_stream()))
+
+    def new_accumulator(self):
+        return torch.zeros(1, dtype=torch.float64, device=self.device)
+
     def eval_step(self, batch, out_y=None):
         with torch.cuda.device(self.device):
             check(self._lib.codae_eval_step(self._h, C.byref(self.bufs), C.byref(batch), ptr(out_y), current_stream()))

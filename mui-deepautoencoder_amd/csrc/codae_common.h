@@ -199,6 +199,8 @@ int mse_loss_colsum_rows(int B);
 int launch_mse_dense(const float* x, const float* y, const float* fmask, float* dy, int64_t n, float inv_n,
                      double* scalars, hipStream_t s);
 int launch_sumsq(const float* g, int64_t n, double* out, hipStream_t s);
+int launch_sumsq_to(const float* g, int64_t n, double* acc, hipStream_t s);      // *acc += sum g^2 (one address, <= 64 blocks)
+int launch_clip_coef(const double* total_sq, float max_norm, double* coef_out, hipStream_t s);
 // coef_in != null: use that precomputed clip coefficient instead of folding grad_sq + slots
 // step_dev != null: take the step count (bias corrections) from that device scalar instead of hp->step
 int launch_clip_adam(float* p, float* g, float* m, float* v, int64_t n, const codae_hyper* hp,

@@ -320,6 +320,26 @@ __global__ __launch_bounds__(NT) void sumsq_kernel(const float* __restrict__ g, 
         atomicAdd(out + (CODAE_S_GRAD_SQ_SLOTS - CODAE_S_GRAD_SQ) + (blockIdx.x & (CODAE_S_N_SLOTS - 1)), (double)b);
 }
 
+// *acc += sum g^2 with at most 64 blocks (a rank's parameter shard in the sharded update): one address, few adders
+__global__ __launch_bounds__(NT) void sumsq_to_kernel(const float* __restrict__ g, int64_t n, double* acc) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const int64_t n4 = n / 4;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < n4; e += (int64_t)gridDim.x * NT) {
+        const float4 v = reinterpret_cast<const float4*>(g)[e];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    for (int64_t e = n4 * 4 + (int64_t)blockIdx.x * NT + threadIdx.x; e < n; e += (int64_t)gridDim.x * NT) s += g[e] * g[e];
+    const float b = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(acc, (double)b);
+}
+
+// clip_grad_norm_'s coefficient from a total sum g^2 (train_dae_on_embedding.py:213): min(1, max_norm / (norm + 1e-6))
+__global__ void clip_coef_kernel(const double* total_sq, float max_norm, double* coef_out) {
+    const float total = sqrtf((float)*total_sq);
+    *coef_out = (double)fminf(1.f, max_norm / (total + 1e-6f));
+}
+
 // ---- a7 + a8: clip scale folded into Adam (torch.optim.Adam, amsgrad off, L2 decay) ----------
 struct AdamConst {
     float lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, wd, max_norm;
@@ -770,6 +790,21 @@ int launch_clip_adam_tiled(float* p, float* g, float* m, float* v, const codae_h
     const int bias_blocks = (int)((bias_n + NT * 8 - 1) / (NT * 8)) > 0 ? (int)((bias_n + NT * 8 - 1) / (NT * 8)) : 1;
     hipLaunchKernelGGL(clip_adam_tiled_kernel, dim3(total + bias_blocks), dim3(NT), 0, s, p, g, m, v, c, grad_sq, shadow, shadow_t,
                        jobs, step_dev);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+int launch_sumsq_to(const float* g, int64_t n, double* acc, hipStream_t s) {
+    CODAE_REQUIRE(g && acc && n > 0, "sumsq_to: bad args");
+    int grid = grid_for(n / 4 + 1);
+    if (grid > 64) grid = 64;
+    hipLaunchKernelGGL(sumsq_to_kernel, dim3(grid), dim3(NT), 0, s, g, n, acc);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+int launch_clip_coef(const double* total_sq, float max_norm, double* coef_out, hipStream_t s) {
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, s, total_sq, max_norm, coef_out);
     CODAE_LAUNCH_CHECK();
     return CODAE_OK;
 }

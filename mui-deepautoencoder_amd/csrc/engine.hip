@@ -912,6 +912,39 @@ int codae_step_update(codae_handle h, const codae_buffers* b, const codae_hyper*
     return update_impl(h, b, hyper, (hipStream_t)stream, false);
 }
 
+int codae_span_sumsq(const float* g, int64_t n, double* acc, void* stream) {
+    return launch_sumsq_to(g, n, acc, (hipStream_t)stream);
+}
+
+int codae_step_update_span(codae_handle h, const codae_buffers* b, const codae_hyper* hyper, int64_t lo, int64_t hi,
+                           const double* total_sq, void* stream) {
+    CODAE_REQUIRE(h && b && hyper, "codae_step_update_span: null argument");
+    CODAE_REQUIRE(b->params && b->grads && b->adam_m && b->adam_v && b->scalars, "codae_step_update_span: buffer missing");
+    CODAE_REQUIRE(lo >= 0 && lo < hi && hi <= h->n_param && lo % 4 == 0 && hi % 4 == 0, "codae_step_update_span: range [%lld, %lld)",
+                  (long long)lo, (long long)hi);
+    CODAE_REQUIRE(hyper->max_grad_norm <= 0.f || total_sq != nullptr, "codae_step_update_span: clipping needs the global sum g^2");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = join_side(h, s);
+    if (rc) return rc;
+    h->norm_scalars_zero = false;
+    const double* coef = nullptr;
+    if (hyper->max_grad_norm > 0.f) {
+        rc = launch_clip_coef(total_sq, hyper->max_grad_norm, b->scalars + CODAE_S_CLIP_COEF, s);
+        if (rc) return rc;
+        coef = b->scalars + CODAE_S_CLIP_COEF;
+    }
+    bf16_t* shadow = h->prec == CODAE_PREC_BF16 ? reinterpret_cast<bf16_t*>(b->shadow_w) : nullptr;
+    CODAE_REQUIRE(h->prec != CODAE_PREC_BF16 || shadow, "codae_step_update_span: shadow_w missing");
+    ProfScope prof(h, CODAE_K_ADAM, s);
+    return launch_clip_adam(b->params + lo, b->grads + lo, b->adam_m + lo, b->adam_v + lo, hi - lo, hyper, nullptr,
+                            shadow ? shadow + lo : nullptr, coef, s);
+}
+
+int codae_sync_transposed(codae_handle h, const codae_buffers* b, void* stream) {
+    CODAE_REQUIRE(h && b, "codae_sync_transposed: null argument");
+    return refresh_transposed(h, b, (hipStream_t)stream);
+}
+
 int codae_join(codae_handle h, void* stream) {
     CODAE_REQUIRE(h != nullptr, "codae_join: null handle");
     return join_side(h, (hipStream_t)stream);

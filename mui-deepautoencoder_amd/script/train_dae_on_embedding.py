@@ -28,7 +28,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from codae.hip import HipError                                            # noqa: E402
 from codae.model.schedule import linear_stack                             # noqa: E402
 from codae.tool import Corrupter, RankingLoss, display_info, get_date, load_dataset_of_embeddings, set_logging  # noqa: E402
-from codae.train import HipEmbeddingTrainer, SubsetEpochSampler           # noqa: E402
+from codae.train import HipEmbeddingTrainer, SubsetEpochSampler, shard_batch   # noqa: E402
 
 
 def parse():
@@ -60,8 +60,10 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        from codae.train import init_rccl_process_group
+        from codae.train import init_rccl_process_group, seed_all_ranks
         init_rccl_process_group(device)
+        # identical sampler order, Corrupter tables and initial weights on every rank (the reference seeds none of them)
+        seed_all_ranks(int(config["SEED"]))
 
     log.info("Loading dataset.")
     dataset = load_dataset_of_embeddings(embedding_path=args.embedding_path, config=config, cache_dir="tmp/")
@@ -116,7 +118,11 @@ def main():
     for epoch in range(epochs):
         log.info("===================================================== EPOCH = %d" % epoch)
         for batch_indices in train_sampler:
-            shard = batch_indices[rank::world] if world > 1 else batch_indices
+            shard = shard_batch(batch_indices, rank, world)
+            if shard is None:                   # fewer rows than ranks (ragged last batch): skipped by every rank
+                nb_skipped = len(batch_indices)
+                log.info("skipping a global batch of %d rows on %d ranks" % (nb_skipped, world))
+                continue
             trainer.train_batch(shard.to(device=device, dtype=torch.int32), run=0, global_rows=len(batch_indices))
         sq, sqp = trainer.epoch_sums()
         book["ftl"].append(np.sqrt(sq / (dataset.nb_predictor * nb_train)))

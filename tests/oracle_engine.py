@@ -50,6 +50,31 @@ class OracleEngine:
             if l > 0:
                 self.d = (self.d @ ps[l][0]).astype(np.float32)
 
+    # ---- sharded update counterparts (DataParallel(sharded=True)) ----
+    step_count = 0
+
+    def new_accumulator(self):
+        return torch.zeros(1, dtype=torch.float64)
+
+    def span_sumsq(self, lo, hi, acc):
+        acc += float((self.grads[lo:hi].double() ** 2).sum())
+
+    def step_update_span(self, hyper, lo, hi, total_sq):
+        g = self.grads.numpy()[lo:hi].copy()
+        total = np.float32(np.sqrt(np.float32(float(total_sq[0]))))
+        g = g * np.float32(min(1.0, hyper["clip"] / (float(total) + 1e-6)))
+        state = {"t": self.t, "m": [(self.m.numpy()[lo:hi], np.zeros(0, np.float32))], "v": [(self.v.numpy()[lo:hi], np.zeros(0, np.float32))]}
+        new = O.adam_step([(self.params.numpy()[lo:hi], np.zeros(0, np.float32))], [(g, np.zeros(0, np.float32))], state,
+                          hyper["lr"], hyper["wd"])
+        self.params[lo:hi] = torch.tensor(new[0][0])
+        self.m[lo:hi] = torch.tensor(state["m"][0][0]); self.v[lo:hi] = torch.tensor(state["v"][0][0])
+
+    def replica_tensors(self):
+        return [self.params]
+
+    def after_replica_sync(self):
+        self.t += 1                              # (one optimizer step done: Adam's t advances once for all spans)
+
     def step_update(self, hyper):
         self.t += 1
         g = self.grads.numpy().copy()

@@ -33,7 +33,7 @@ def _problem():
     return sched, params, x, fmask
 
 
-def _worker(rank, world, port, out_dir, n_buckets):
+def _worker(rank, world, port, out_dir, n_buckets, sharded=False):
     for p in (os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "mui-deepautoencoder_amd"), HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -46,7 +46,7 @@ def _worker(rank, world, port, out_dir, n_buckets):
     eng = OracleEngine(sched, params)
     if rank != 0:
         eng.params.zero_()                      # must be overwritten by the broadcast
-    dp = DataParallel(eng, n_buckets=n_buckets)
+    dp = DataParallel(eng, n_buckets=n_buckets, sharded=sharded)
     dp.broadcast_params(eng.params)
     B = x.shape[0]
     lo, hi = rank * B // world, (rank + 1) * B // world
@@ -54,6 +54,9 @@ def _worker(rank, world, port, out_dir, n_buckets):
     for _ in range(3):
         dp.train_step((x[lo:hi], fmask[lo:hi]), hyper, hi - lo)
     sq = dp.reduce_scalars(torch.tensor([eng.sq], dtype=torch.float64))
+    if sharded:
+        np.save(os.path.join(out_dir, "replica_%d.npy" % rank), eng.params.numpy().copy())   # what the next step would read
+        dp.gather_params()
     np.save(os.path.join(out_dir, "params_%d.npy" % rank), eng.params.numpy())
     np.save(os.path.join(out_dir, "sq_%d.npy" % rank), sq.numpy())
     dist.destroy_process_group()
@@ -81,3 +84,29 @@ def test_two_ranks_match_single_process(tmp_path, n_buckets):
     assert default_buckets(6, 4) == [(4, 6), (2, 4), (1, 2), (0, 1)]
     assert default_buckets(1, 4) == [(0, 1)]
     assert sorted(sum([list(range(a, b)) for a, b in default_buckets(10, 3)], [])) == list(range(10))
+
+
+@pytest.mark.parametrize("world,n_buckets", [(2, 4), (4, 1), (4, 8)])
+def test_sharded_update_matches_single_process(tmp_path, world, n_buckets):
+    """Reduce-scatter -> clip + Adam on 1/N of each bucket -> all-gather (DataParallel(sharded=True)), world 2 and 4, with
+    4 buckets, one bucket, and one bucket PER LAYER (8 layers): every rank ends with the same bytes, and they are the
+    single-process global-batch run's parameters."""
+    sys.path.insert(0, HERE)
+    from codae.train import DataParallel
+    from oracle_engine import OracleEngine
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), n_buckets, True), nprocs=world, join=True)
+    sched, params, x, fmask = _problem()
+    assert len(sched) == 8
+    ref = OracleEngine(sched, params)
+    dp = DataParallel(ref)
+    hyper = {"global_rows": x.shape[0], "clip": 1.0, "lr": 1e-2, "wd": 1e-4}
+    for _ in range(3):
+        dp.train_step((x, fmask), hyper, x.shape[0])
+    ps = [np.load(tmp_path / ("params_%d.npy" % r)) for r in range(world)]
+    rs = [np.load(tmp_path / ("replica_%d.npy" % r)) for r in range(world)]
+    for r in range(1, world):
+        assert np.array_equal(ps[0], ps[r]), "gathered parameters differ between ranks"
+        assert np.array_equal(rs[0], rs[r]), "replicas (what the next forward reads) diverged"
+    assert np.array_equal(ps[0], rs[0])          # (oracle engine: the replicated tensor IS the fp32 parameter vector)
+    assert np.allclose(ps[0], ref.params.numpy(), rtol=1e-4, atol=1e-6)
+    assert abs(float(np.load(tmp_path / "sq_0.npy")[0]) - ref.sq) < 1e-3 * ref.sq

@@ -324,3 +324,25 @@ def test_isa_guard_detects_the_hazards_it_exists_for():
     assert any("v_add_u32_e32" in e for e in C.check_kernel("k", name, kernel(waw)))
     drained = clean[:2] + [("s_waitcnt", "vmcnt(0)")] + clean[3:]
     assert any("vmcnt(0)" in e for e in C.check_kernel("k", name, kernel(drained)))
+
+
+def test_shard_batch_skips_batches_smaller_than_the_world():
+    """a ragged last batch with fewer rows than ranks used to leave the high ranks with an empty shard (their
+    launch fails, the others hang in the all-reduce).  shard_batch gives every rank the same verdict."""
+    from codae.train import shard_batch, seed_all_ranks
+    b = torch.arange(10)
+    assert torch.equal(shard_batch(b, 0, 1), b)
+    parts = [shard_batch(b, r, 4) for r in range(4)]
+    assert sorted(torch.cat(parts).tolist()) == list(range(10)) and all(len(p) >= 2 for p in parts)
+    assert all(shard_batch(torch.arange(3), r, 4) is None for r in range(4))
+    assert all(shard_batch(torch.arange(1), r, 2) is None for r in range(2))
+    assert [len(shard_batch(torch.arange(4), r, 4)) for r in range(4)] == [1, 1, 1, 1]
+    # same seed on every rank -> same mask tables and sampler order
+    from codae.tool import Corrupter
+    arch = [{"size": 4, "position": 4 * s} for s in range(3)]
+    tabs = []
+    for _ in range(2):
+        seed_all_ranks(1234)
+        c = Corrupter(nb_observation=20, arch=arch, k_max=1, device=torch.device("cpu"))
+        tabs.append((c.mask_to_use.clone(), torch.randperm(7)))
+    assert torch.equal(tabs[0][0], tabs[1][0]) and torch.equal(tabs[0][1], tabs[1][1])
