@@ -578,15 +578,21 @@ int gemm_bf16_tile_big(int M, int N, int split_k, bool k_strided = false) {
     //   wgrad + slab reduce (KS x KS, split-K 5)                           68.1  55.1  55.3  53.9
     // (before the transposed LDS reads went to inline asm the k-strided forms of q ran 53 / 62 us: the
     // compiler drained vmcnt to 0 in front of each of them)
+    // r02, same box, interleaved (us): tile                                   q     x
+    //   forward                                                             34.3  33.9
+    //   dgrad through W itself                                              45.6  44.9
+    //   wgrad + slab reduce                                                 50.7  49.3      whole step 1.398 -> 1.362 ms
+    // (x = q with every LDS-DMA piece issued by waves 0..3, one per SIMD: the SIMD partner multiplies while its
+    // neighbour's issue slots are taken by the VMEM instructions)
     (void)k_strided;
     if (big < 160) return 0;
-    return 3;
+    return 6;
 }
 
 // rows of g.colsum_part the launch gemm_bf16(g) makes will write: one per tile along M of the tile it picks
 int gemm_bf16_colsum_rows(const GemmBf16& g) {
     const int t = gemm_bf16_tile_big(g.M, g.N, g.loss.enabled ? 1 : g.split_k, g.b_mode == OP_KS || g.c_f32);
-    const int bm = g.loss.enabled ? (t ? 256 : 128) : ((t == 1 || t == 2 || t == 3 || t == 5) ? 256 : 128);
+    const int bm = g.loss.enabled ? (t ? 256 : 128) : ((t == 1 || t == 2 || t == 3 || t == 5 || t == 6) ? 256 : 128);
     return (g.M + bm - 1) / bm;
 }
 
@@ -621,12 +627,13 @@ int gemm_bf16(const GemmBf16& g, hipStream_t s) {
     if (g.loss.enabled) {
         const int t = gemm_bf16_tile_big(g.M, g.N, 1);
         if (t == 1) return launch_cfg<256, 192, 4, 2>(g, s);      // (CODAE_GEMM_TILE=b: round 1's fused-loss kernel)
-        if (t) return gemm_bf16_pipe(g, 1, s);                    // 8-wave pipelined kernel, loss from the accumulators
+        if (t) return gemm_bf16_pipe(g, t == 6 ? 6 : 1, s);       // 8-wave pipelined kernel, loss from the accumulators
         return launch_cfg<128, 128, 2, 2>(g, s);
     }
     switch (gemm_bf16_tile_big(g.M, g.N, g.split_k, g.b_mode == OP_KS || g.c_f32)) {
         case 2: return gemm_bf16_pipe(g, 0, s);               // 256 x 192, 4 waves, phase-pipelined
         case 3: return gemm_bf16_pipe(g, 1, s);               // 256 x 192, 8 waves, phase-pipelined (forward default)
+        case 6: return gemm_bf16_pipe(g, 6, s);               // 256 x 192, 8 waves, LDS-DMA issued by one wave per SIMD
         case 1: return launch_cfg<256, 192, 4, 2>(g, s);      // 256 x 192, 8 waves, one barrier per K-tile
         case 4: return launch_cfg<128, 192, 2, 2>(g, s);      // 128 x 192, 4 waves, 80 KiB LDS: two workgroups per CU
         default: return launch_cfg<128, 128, 2, 2>(g, s);

@@ -206,7 +206,8 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
     // (likewise the A half-tile by the first NLA waves when its pieces do not divide over all of them.  A 12-wave
     // form - 4 x 3 waves of 64 x 64, three per SIMD, 150 VGPRs - was measured: forward 36.2 vs 36.1 us for 8 waves,
     // wgrad 54.6 vs 50.7: occupancy is not what limits the K loop; it is not instantiated)
-    constexpr int NLA = ((AHR / 8) % NW == 0) ? NW : 8;
+    // NLB == 4 with 8 waves: waves 0..3 - one per SIMD - carry ALL LDS-DMA pieces (A and B), their SIMD partners 4..7 none
+    constexpr int NLA = (NLB == 4 && NW == 8) ? 4 : (((AHR / 8) % NW == 0) ? NW : 8);
     constexpr int NA = AHR / 8 / NLA, NB = BHR / 8 / NLB;
     static_assert(NLB <= NW && NLA <= NW && (AHR / 8) % NLA == 0 && (BHR / 8) % NLB == 0, "loader waves");
     static_assert(SM % 32 == 0 && SN % 32 == 0, "wave sub-tile must split into 16-wide half tiles");
@@ -801,7 +802,9 @@ int gemm_bf16_pipe(const GemmBf16& g, int cfg, hipStream_t s) {
             default: break;
         }
     }
-    if (cfg == 1) return launch_pipe<256, 192, 4, 2, 6>(g, s);   // 8 waves (64 x 96 per wave), B halves by 6 loader waves
+    // CODAE_GEMM_TILE=x: all LDS-DMA pieces on waves 0..3 (one per SIMD), their SIMD partners 4..7 only multiply
+    if (cfg == 6) return launch_pipe<256, 192, 4, 2, 4>(g, s);
+    if (cfg == 1 || cfg >= 6) return launch_pipe<256, 192, 4, 2, 6>(g, s);   // 8 waves (64 x 96 per wave), B halves by 6 loader waves
     return launch_pipe<256, 192, 2, 2, 4>(g, s);                 // 4 waves (128 x 96 per wave)
 }
 

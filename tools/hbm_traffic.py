@@ -29,11 +29,12 @@ def classify(name):
         a_mode, b_mode, c_f32, epi = args[5], args[6], args[7], args[9] if len(args) > 9 else "0"
         if c_f32 == "true":
             return "gemm_wgrad"
-        return "gemm_dgrad" if epi == "2" else "gemm_fwd"
+        return {"2": "gemm_dgrad", "3": "loss_gemm"}.get(epi, "gemm_fwd")
     if "gemm_bf16_kernel" in name and name.replace(" ", "").endswith("true>(codae::GemmBf16,int,int,int)"):
         return "loss_gemm"
     for key, cls in (("clip_adam_tiled", "adam_tiled"), ("clip_adam", "adam"), ("reduce_slabs", "slab_reduce"), ("gather_corrupt", "gather"),
-                     ("transpose_bf16", "transpose"), ("cast_bf16", "cast_bf16")):
+                     ("transpose_bf16", "transpose"), ("cast_bf16", "cast_bf16"), ("bias_finish", "bias_finish"), ("chain_step", "chain"),
+                     ("gemm_bf16_grouped", "wgrad_grouped")):
         if key in name:
             return cls
     return None
@@ -50,7 +51,8 @@ def main():
         w = write.get(name, 0.0)
         out[cls] = {"bytes_per_launch": (2.0 * f + w) * 1024.0, "read": 2.0 * f * 1024.0, "written": w * 1024.0,
                     "launches_sampled": nf[name]}
-    res = {k: v["bytes_per_launch"] for k, v in out.items() if k.startswith("gemm_")}
+    res = {k: v["bytes_per_launch"] for k, v in out.items() if k.startswith("gemm_") or k in ("loss_gemm", "chain", "wgrad_grouped")}
+    res["loss"] = res.get("loss_gemm")
     res["_detail"] = out
     res["_unit"] = ("bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts half of wide "
                     "coalesced reads; MI355X_MICROARCH.md, HBM section); fabric traffic of the XCD L2s, Infinity-Cache "
