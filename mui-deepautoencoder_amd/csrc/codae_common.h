@@ -82,9 +82,9 @@ static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * 
 // CODAE_* tuning / ablation variables, read ONCE (library load, codae_create, codae_reload_env): nothing on the
 // launch path calls getenv (round 1 did, ~30 times per step)
 struct EnvToggles {
-    int gemm_tile = -1;          // CODAE_GEMM_TILE s|b|p|q|c|w -> 0..5, -1 = automatic
+    int gemm_tile = -1;          // CODAE_GEMM_TILE: s = 128 x 128 (0), q = 256 x 192 pipelined, every wave loads (3),
+                                 // x = 256 x 192 pipelined, LDS-DMA on one wave per SIMD (6); -1 = automatic
     int gemm_dbg = 0;            // CODAE_GEMM_DBG timing-only ablation builds of the forward form
-    bool gemm_dbg8 = false;      // CODAE_GEMM_DBG8: ablations on the 8-wave form
     int wgrad_splitk = 0;        // CODAE_WGRAD_SPLITK > 0 forces the split
     bool side_priority_set = false; int side_priority = 0;   // CODAE_SIDE_PRIORITY
     bool no_wt = false, single_stream = false, tail_on_side = false, no_fused_loss = false, flat_adam = false,

@@ -26,12 +26,9 @@ static bool g_env_loaded = false;
 void env_reload() {
     EnvToggles e;
     if (const char* t = getenv("CODAE_GEMM_TILE")) {
-        switch (t[0]) { case 's': e.gemm_tile = 0; break; case 'b': e.gemm_tile = 1; break; case 'p': e.gemm_tile = 2; break;
-                        case 'q': e.gemm_tile = 3; break; case 'c': e.gemm_tile = 4; break; case 'w': e.gemm_tile = 5; break;
-                        case 'x': e.gemm_tile = 6; break; default: break; }
+        switch (t[0]) { case 's': e.gemm_tile = 0; break; case 'q': e.gemm_tile = 3; break; case 'x': e.gemm_tile = 6; break; default: break; }
     }
     if (const char* d = getenv("CODAE_GEMM_DBG")) e.gemm_dbg = atoi(d);
-    e.gemm_dbg8 = getenv("CODAE_GEMM_DBG8") != nullptr;
     if (const char* k = getenv("CODAE_WGRAD_SPLITK")) e.wgrad_splitk = atoi(k) > 0 ? atoi(k) : 0;
     if (const char* pr = getenv("CODAE_SIDE_PRIORITY")) { e.side_priority_set = true; e.side_priority = atoi(pr); }
     e.no_wt = getenv("CODAE_NO_WT") != nullptr;

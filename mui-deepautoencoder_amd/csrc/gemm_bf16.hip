@@ -525,10 +525,6 @@ int launch_cfg(const GemmBf16& g, hipStream_t s) {
 #define LAUNCH(AM, BMODE, CF) \
     hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, AM, BMODE, CF>), grid, block, 0, s, g, tiles_n, tiles_m * tiles_n, kt_total)
     if (g.loss.enabled) {
-        // (the fused-loss form is built for the one-workgroup-per-CU tiles only: its row table would push the
-        // 128 x 192 tile past the 80 KiB that lets two workgroups share a CU)
-        if constexpr (BM == 128 && BN == 192) { set_error("gemm_bf16: fused loss is not built for the 128 x 192 tile"); return CODAE_E_UNSUPPORTED; }
-        else
         hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, OP_KC, OP_KC, false, true>), grid, block, 0, s, g, tiles_n,
                            tiles_m * tiles_n, kt_total);
     } else if (g.a_mode == OP_KC && g.b_mode == OP_KC) { if (g.c_f32) LAUNCH(OP_KC, OP_KC, true); else LAUNCH(OP_KC, OP_KC, false); }
@@ -571,13 +567,9 @@ bool gemm_bf16_supported(int M, int N, int K) {
 int gemm_bf16_tile_big(int M, int N, int split_k, bool k_strided = false) {
     if (env().gemm_tile >= 0) return env().gemm_tile;
     const int64_t big = (int64_t)((M + 255) / 256) * ((N + 191) / 192) * split_k;
-    // measured (tools/bench_gemm.py, 8192 x 1536 x 1536, us): tile            s     b     c     q
-    //   forward (KC x KC)                                                  46.3  38.4  40.2  37.0
-    //   dgrad through W itself (KC x KS; the engine uses the transposed shadow = forward form)
-    //                                                                      59.6  46.4  44.9  43.3
-    //   wgrad + slab reduce (KS x KS, split-K 5)                           68.1  55.1  55.3  53.9
-    // (before the transposed LDS reads went to inline asm the k-strided forms of q ran 53 / 62 us: the
-    // compiler drained vmcnt to 0 in front of each of them)
+    // round 1 (tools/bench_gemm.py, 8192 x 1536 x 1536, us): 128 x 128 (s) 46.3 / 59.6 / 68.1 for forward / dgrad through W /
+    // wgrad + reduce; one-barrier 256 x 192 (b) 38.4 / 46.4 / 55.1; two 128 x 192 workgroups per CU (c) 40.2 / 44.9 / 55.3;
+    // 4-wave pipelined (p) slower than 8-wave (q) 37.0 / 43.3 / 53.9.  b, c and p were pruned in round 2.
     // r02, same box, interleaved (us): tile                                   q     x
     //   forward                                                             34.3  33.9
     //   dgrad through W itself                                              45.6  44.9
@@ -592,7 +584,7 @@ int gemm_bf16_tile_big(int M, int N, int split_k, bool k_strided = false) {
 // rows of g.colsum_part the launch gemm_bf16(g) makes will write: one per tile along M of the tile it picks
 int gemm_bf16_colsum_rows(const GemmBf16& g) {
     const int t = gemm_bf16_tile_big(g.M, g.N, g.loss.enabled ? 1 : g.split_k, g.b_mode == OP_KS || g.c_f32);
-    const int bm = g.loss.enabled ? (t ? 256 : 128) : ((t == 1 || t == 2 || t == 3 || t == 5 || t == 6) ? 256 : 128);
+    const int bm = g.loss.enabled ? (t ? 256 : 128) : (t ? 256 : 128);
     return (g.M + bm - 1) / bm;
 }
 
@@ -626,17 +618,14 @@ int gemm_bf16(const GemmBf16& g, hipStream_t s) {
     if (env().gemm_dbg) { GemmBf16 g2 = g; g2.dbg = env().gemm_dbg; return gemm_bf16_pipe(g2, 0, s); }
     if (g.loss.enabled) {
         const int t = gemm_bf16_tile_big(g.M, g.N, 1);
-        if (t == 1) return launch_cfg<256, 192, 4, 2>(g, s);      // (CODAE_GEMM_TILE=b: round 1's fused-loss kernel)
-        if (t) return gemm_bf16_pipe(g, t == 6 ? 6 : 1, s);       // 8-wave pipelined kernel, loss from the accumulators
+        if (t) return gemm_bf16_pipe(g, t >= 6 ? 6 : 1, s);       // 8-wave pipelined kernel, loss from the accumulators
         return launch_cfg<128, 128, 2, 2>(g, s);
     }
-    switch (gemm_bf16_tile_big(g.M, g.N, g.split_k, g.b_mode == OP_KS || g.c_f32)) {
-        case 2: return gemm_bf16_pipe(g, 0, s);               // 256 x 192, 4 waves, phase-pipelined
-        case 3: return gemm_bf16_pipe(g, 1, s);               // 256 x 192, 8 waves, phase-pipelined (forward default)
-        case 6: return gemm_bf16_pipe(g, 6, s);               // 256 x 192, 8 waves, LDS-DMA issued by one wave per SIMD
-        case 1: return launch_cfg<256, 192, 4, 2>(g, s);      // 256 x 192, 8 waves, one barrier per K-tile
-        case 4: return launch_cfg<128, 192, 2, 2>(g, s);      // 128 x 192, 4 waves, 80 KiB LDS: two workgroups per CU
-        default: return launch_cfg<128, 128, 2, 2>(g, s);
+    const int t = gemm_bf16_tile_big(g.M, g.N, g.split_k, g.b_mode == OP_KS || g.c_f32);
+    switch (t) {
+        case 3: return gemm_bf16_pipe(g, 1, s);               // 256 x 192, 8 waves, phase-pipelined, every wave loads
+        case 6: return gemm_bf16_pipe(g, 6, s);               // 256 x 192, 8 waves, LDS-DMA issued by one wave per SIMD (default)
+        default: return launch_cfg<128, 128, 2, 2>(g, s);     // small problems: one-barrier double buffer
     }
 }
 

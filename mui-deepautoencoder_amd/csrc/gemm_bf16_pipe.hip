@@ -28,160 +28,19 @@
 // issue).  Both orders hold by construction, not by timing (MI355X guide: "Read a staged buffer one phase AFTER
 // the wait that retires it").  Loads past the last K-tile are issued as dummies, so the counts stay exact.
 //
-// Configurations (4 waves = one per SIMD, the whole 512-entry register file per wave):
-//   256 x 192 (2 x 2 waves, 128 x 96 per wave, a = 4, b = 3): 8192 x 1536 outputs = 256 workgroups
-//   256 x 256 (2 x 2 waves, 128 x 128 per wave, a = b = 4)
+// Configuration: 256 x 192, 8 waves (4 x 2, 64 x 96 per wave, two per SIMD): 8192 x 1536 outputs = 256 workgroups = one per
+// CU.  LDS-DMA pieces either on every wave (A: a = 2 per half; B: b = 2 on 6 of the 8 waves) or, the default, on waves
+// 0..3 only - one per SIMD - with a = 4, b = 3.  (Round 1 also built a 4-wave form, one wave per
+// SIMD with the whole register file: slower, limited by VGPR <-> AGPR moves; pruned.  Round 2 tried an alternating-order
+// schedule with single fragment register sets, to hold 64 x 128 accumulator blocks for asymmetric loader / multiplier
+// roles and a 256 x 256 tile: the 256 x 192 form ran 34.9 vs 34.1 us, the 256 x 256 form spilled; removed.)
 #include "codae_common.h"
 #include <type_traits>
 
 namespace codae {
 namespace {
 
-constexpr int BK = 64;
-
-typedef __attribute__((address_space(3))) char lds_char;
-typedef __attribute__((address_space(1))) const void gvoid;
-
-__device__ __forceinline__ void glds16(const void* gsrc, lds_char* dst_wave_base) {
-    __builtin_amdgcn_global_load_lds((gvoid*)gsrc, (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// All but the wave's KEEP youngest LDS reads have returned; then the workgroup barrier.  The LDS-DMA issued after
-// the barrier overwrites a region whose last readers ran TWO phases ago, so the reads of the phase just finished
-// (KEEP of them, compiler-visible ds_read_b128 only) may stay in flight across it.
-template <int KEEP = 0>
-__device__ __forceinline__ void phase_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(KEEP) : "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
-// Tell the scheduler to spread a phase's LDS reads and LDS-DMA issues between its MFMAs instead of
-// clumping them in front: at one wave per SIMD nothing else would overlap their issue cost.
-template <int N_MFMA, int N_DS, int N_VMEM>
-__device__ __forceinline__ void interleave() {
-    constexpr int ITEMS = N_DS + N_VMEM;
-    constexpr int PER = (N_MFMA / ITEMS) > 0 ? (N_MFMA / ITEMS) : 1;
-#pragma unroll
-    for (int i = 0; i < N_DS; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);   // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
-    }
-#pragma unroll
-    for (int i = 0; i < N_VMEM; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
-        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);     // VMEM (LDS-DMA)
-    }
-    constexpr int REST = N_MFMA - PER * ITEMS;
-    if constexpr (REST > 0) __builtin_amdgcn_sched_group_barrier(0x008, REST, 0);
-}
-
-// ---- half-tile images ------------------------------------------------------------------------
-// Half-tile h is the contiguous range [h * RH, (h+1) * RH) of the tile's rows (columns); inside it wave row
-// (column) w owns [w * S/2, (w+1) * S/2).  So a wave's two halves are RH apart in the output, and a k-strided
-// half image fetches ONE contiguous 2*RH-byte segment per k-row (interleaving the waves' halves instead fetched
-// two half-used segments and cost 20-35 % on the dgrad / wgrad forms).
-template <int S>
-__device__ __forceinline__ int half_to_tile(int l, int h, int RH) {
-    return h * RH + l;
-}
-
-// KS image of a half: [64 k-rows][RH columns], 32-B blocks swizzled per k-row so that the 8 rows
-// one 32-lane half of ds_read_b64_tr_b16 touches fall on 8 different 32-B slots:
-//   RH = 128 (256-B rows): block' = block ^ ((kr & 3) | (((kr >> 3) & 1) << 2))
-//   RH =  96 (192-B rows, slot = (6 kr + block') mod 8): block' = (block + ((kr >> 3) & 1)) mod 6
-template <int RH>
-__device__ __forceinline__ int ks_to_lds_block(int block, int kr) {
-    if constexpr (RH == 96) {
-        const int b = block + ((kr >> 3) & 1);
-        return b >= 6 ? b - 6 : b;
-    } else {
-        static_assert(RH == 128, "KS half image: 96 or 128 columns");
-        return block ^ ((kr & 3) | (((kr >> 3) & 1) << 2));
-    }
-}
-template <int RH>
-__device__ __forceinline__ int ks_from_lds_block(int lds_block, int kr) {
-    if constexpr (RH == 96) {
-        const int b = lds_block - ((kr >> 3) & 1);
-        return b < 0 ? b + 6 : b;
-    } else {
-        return lds_block ^ ((kr & 3) | (((kr >> 3) & 1) << 2));
-    }
-}
-
-// Global source (at k = 0), as a BYTE OFFSET from the operand's base, of the 16 bytes lane `lane` of loader wave `w`
-// places with its `it`-th LDS-DMA instruction of half-tile h (instruction j = it * NW + w writes img + j * 1024 +
-// lane * 16).  Everything here is loop invariant; the K advance is wave-uniform and goes into the scalar base, so the
-// DMA instruction takes {SGPR base, 32-bit VGPR offset}: half the address registers of per-lane 64-bit pointers and no
-// 64-bit VALU add per issue (operands are < 4 GiB: checked at launch).
-template <int MODE, int RH, int S, int NW>
-__device__ __forceinline__ uint32_t half_src(int64_t ld, int r0, int rmax, int h, int it, int w, int lane) {
-    const int j = it * NW + w;
-    if constexpr (MODE == OP_KC) {
-        const int lr = j * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((lr >> 1) & 7);
-        int grow = r0 + half_to_tile<S>(lr, h, RH);
-        grow = grow < rmax ? grow : rmax - 1;
-        return (uint32_t)(((int64_t)grow * ld + c * 8) * 2);
-    } else {
-        constexpr int CPR = RH / 8;
-        const int q = j * 64 + lane;
-        const int kr = q / CPR;
-        const int cp = q - kr * CPR;
-        const int lc = (ks_from_lds_block<RH>(cp >> 1, kr) * 2 + (cp & 1)) * 8;
-        int col = r0 + half_to_tile<S>(lc, h, RH);
-        col = col + 8 <= rmax ? col : rmax - 8;
-        return (uint32_t)(((int64_t)kr * ld + col) * 2);
-    }
-}
-
-// ds_read_b64_tr_b16 issued behind the compiler's back.  A transposed LDS read the compiler knows about
-// gets an `s_waitcnt vmcnt(0)` in front of it whenever LDS-DMA loads are in flight (it cannot tell the
-// images apart), which drains the whole 7-phase prefetch queue in every phase.  The kernel's own
-// protocol already orders these reads: every fragment is consumed only after the next phase_barrier()
-// (s_waitcnt lgkmcnt(0) + s_barrier), where settle() hands the registers back to the compiler.
-template <int OFF>
-__device__ __forceinline__ s16x4 lds_read_tr16(const lds_char* p) {
-    s16x4 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"((uint32_t)(uintptr_t)p), "n"(OFF));
-    return v;
-}
-// after the wait that covers their reads: MFMAs consuming `f` cannot be scheduled above this point
-template <int N>
-__device__ __forceinline__ void settle(bf16x8 (&f)[N][2]) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        asm volatile("" : "+v"(f[i][0]));
-        asm volatile("" : "+v"(f[i][1]));
-    }
-}
-
-// 8-element MFMA fragment: 16-wide tile `t` (local to the half image), k-step S.
-template <int MODE, int RH, int S>
-__device__ __forceinline__ bf16x8 read_frag(const lds_char* img, int t, int lane) {
-    if constexpr (MODE == OP_KC) {
-        const int r = lane & 15, g = lane >> 4;
-        const int off = (16 * t + r) * 128 + (((4 * S + g) ^ (r >> 1)) << 4);
-        const s16x8 v = *reinterpret_cast<const __attribute__((address_space(3))) s16x8*>(img + off);
-        return __builtin_bit_cast(bf16x8, v);
-    } else {
-        // the swizzle key depends on (kr & 3) and ((kr >> 3) & 1) only, i.e. not on the k-step: both k-steps read from
-        // ONE address register, the second through the instruction's offset field (half the address VGPRs)
-        const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-        const int kr = 8 * g + q;
-        const int off = kr * (2 * RH) + (ks_to_lds_block<RH>(t, kr) << 5) + 8 * p;
-        const s16x4 lo = lds_read_tr16<S * 32 * 2 * RH>(img + off);
-        const s16x4 hi = lds_read_tr16<S * 32 * 2 * RH + 4 * 2 * RH>(img + off);
-        const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        return __builtin_bit_cast(bf16x8, v);
-    }
-}
+#include "gemm_bf16_halftile.h"
 
 // DBG = 8 build only: per-workgroup wall-clock stamps (100 MHz s_memrealtime) at entry, first MFMA phase,
 // end of the K loop, epilogue stores issued, stores retired; + the XCC the workgroup ran on
@@ -373,8 +232,6 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
     read_b(b0, 0, 0);
 
     stamp(1);
-    constexpr int N_MMA = 2 * TMH * TNH;
-    constexpr int RD_A = 2 * TMH * (A_MODE == OP_KC ? 1 : 2), RD_B = 2 * TNH * (B_MODE == OP_KC ? 1 : 2);
     // reads that may stay in flight across the barrier after a phase that read an A / a B half: the compiler-visible
     // ds_read_b128 of a k-contiguous operand (it waits for them itself before their first use); the asm-issued
     // transposed reads of a k-strided operand are waited for in full (settle() follows the barrier)
@@ -390,7 +247,6 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
         issue_a(t + 2, 0);
         read_a(a1, t, 1);
         mma(a0, b0, 0, 0);
-        if constexpr (NW == 4) interleave<N_MMA, RD_A, NA>();
         // P2: A1 x B0
         wait_for_b();
         phase_barrier<KEEP_A>();
@@ -398,7 +254,6 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
         issue_b(t + 2, 0);
         read_b(b1, t, 1);
         mma(a1, b0, 1, 0);
-        if constexpr (NW == 4) interleave<N_MMA, RD_B, NB>();
         // P3: A1 x B1
         wait_for_a();
         phase_barrier<KEEP_B>();
@@ -406,14 +261,12 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
         issue_a(t + 2, 1);
         read_a(a0n, t + 1, 0);
         mma(a1, b1, 1, 1);
-        if constexpr (NW == 4) interleave<N_MMA, RD_A, NA>();
         // P4: A0 x B1
         wait_for_b();
         phase_barrier<KEEP_A>();
         issue_b(t + 2, 1);
         read_b(b0, t + 1, 0);
         mma(a0, b1, 0, 1);
-        if constexpr (NW == 4) interleave<N_MMA, RD_B, NB>();
     };
     int t = 0;
     for (; t + 1 < nkt; t += 2) {
@@ -768,12 +621,8 @@ template <int DBG>
 int launch_dbg(const GemmBf16& g, hipStream_t s) {
     constexpr int BM = 256, BN = 192;
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-    if (env().gemm_dbg8)   // the 8-wave form
-        hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, 4, 2, 6, OP_KC, OP_KC, false, DBG>), dim3(tiles_m * tiles_n), dim3(512), 0, s, g,
-                           tiles_n, tiles_m * tiles_n, g.K / BK);
-    else
-        hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, 2, 2, 4, OP_KC, OP_KC, false, DBG>), dim3(tiles_m * tiles_n), dim3(256), 0, s, g,
-                           tiles_n, tiles_m * tiles_n, g.K / BK);
+    hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, 4, 2, 4, OP_KC, OP_KC, false, DBG>), dim3(tiles_m * tiles_n), dim3(512), 0, s, g,
+                       tiles_n, tiles_m * tiles_n, g.K / BK);
     CODAE_LAUNCH_CHECK();
     return CODAE_OK;
 }
@@ -804,8 +653,7 @@ int gemm_bf16_pipe(const GemmBf16& g, int cfg, hipStream_t s) {
     }
     // CODAE_GEMM_TILE=x: all LDS-DMA pieces on waves 0..3 (one per SIMD), their SIMD partners 4..7 only multiply
     if (cfg == 6) return launch_pipe<256, 192, 4, 2, 4>(g, s);
-    if (cfg == 1 || cfg >= 6) return launch_pipe<256, 192, 4, 2, 6>(g, s);   // 8 waves (64 x 96 per wave), B halves by 6 loader waves
-    return launch_pipe<256, 192, 2, 2, 4>(g, s);                 // 4 waves (128 x 96 per wave)
+    return launch_pipe<256, 192, 4, 2, 6>(g, s);                 // 8 waves (64 x 96 per wave), B halves by 6 loader waves
 }
 
 // copies the DBG = 8 stamps of the first n_wg workgroups (TIMELINE_SLOTS words each) to the host

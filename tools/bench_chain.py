@@ -39,7 +39,7 @@ def timeit(fn, n=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 
-tiles = sys.argv[1].split(",") if len(sys.argv) > 1 else ["b", "c", "q"]
+tiles = sys.argv[1].split(",") if len(sys.argv) > 1 else ["q", "x"]
 for rnd in range(3):
     for tile in tiles:
         os.environ["CODAE_GEMM_TILE"] = tile

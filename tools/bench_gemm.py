@@ -23,7 +23,7 @@ def fwd(): hip.check(L.codae_linear_bf16(hip.ptr(x), hip.ptr(W), hip.ptr(b), hip
 def dgrad(): hip.check(L.codae_dgrad_bf16(hip.ptr(dy), hip.ptr(W), hip.ptr(h), hip.ptr(dx), hip.ptr(db), hip.ptr(dbws), M, N, K, st))
 def wgrad(): hip.check(L.codae_wgrad_bf16(hip.ptr(dy), hip.ptr(x), hip.ptr(dW), hip.ptr(slabs), slabs.numel() * 4, M, N, K, st))
 ops = {"fwd": fwd, "dgrad": dgrad, "wgrad(+reduce)": wgrad}
-cfgs = sys.argv[4].split(",") if len(sys.argv) > 4 else ["s", "b", "c", "q"]
+cfgs = sys.argv[4].split(",") if len(sys.argv) > 4 else ["s", "q", "x"]
 res = {(o, c): [] for o in ops for c in cfgs}
 for rnd in range(6):
     for c in cfgs:

@@ -66,7 +66,7 @@ def demangle(names):
     """{mangled: 'kernel<a, b, ...>'} from the Itanium-mangled integer / bool template arguments (no c++filt needed)."""
     out = {}
     for n in names:
-        m = re.search(r"(gemm_bf16(?:_pipe)?_kernel)I((?:L[ib]\d+E)+)E", n)
+        m = re.search(r"(gemm_bf16(?:_pipe|_snake)?_kernel)I((?:L[ib]\d+E)+)E", n)
         if m:
             out[n] = "%s<%s>" % (m.group(1), ", ".join(re.findall(r"L[ib](\d+)E", m.group(2))))
         else:
@@ -116,10 +116,14 @@ def loops_with_mfma(insns):
 
 def check_kernel(name, pretty, insns):
     errs = []
-    is_pipe = "gemm_bf16_pipe_kernel" in pretty
+    is_snake = "gemm_bf16_snake_kernel" in pretty
+    is_pipe = "gemm_bf16_pipe_kernel" in pretty or is_snake          # (phase-pipelined: counted vmcnt only in the K loop)
     args = [a.strip() for a in pretty[pretty.index("<") + 1:pretty.rindex(">")].split(",")]
-    a_mode, b_mode = (int(args[5]), int(args[6])) if is_pipe else (int(args[4]), int(args[5]))
-    dbg = int(args[8]) if is_pipe and len(args) > 8 else 0
+    if is_snake:
+        a_mode, b_mode = int(args[3]), int(args[4])
+    else:
+        a_mode, b_mode = (int(args[5]), int(args[6])) if is_pipe else (int(args[4]), int(args[5]))
+    dbg = int(args[8]) if (is_pipe and not is_snake and len(args) > 8) else 0
     k_strided = a_mode == 1 or b_mode == 1
     n_tr = sum(1 for _, o, _ in insns if o == "ds_read_b64_tr_b16")
     if k_strided and n_tr == 0:
@@ -189,6 +193,9 @@ def main():
         if "gemm_bf16_pipe_kernel" in p:
             a = [x.strip() for x in p[p.index("<") + 1:p.rindex(">")].split(",")]
             n_ks += int(a[5] == "1" or a[6] == "1")
+        if "gemm_bf16_snake_kernel" in p:
+            a = [x.strip() for x in p[p.index("<") + 1:p.rindex(">")].split(",")]
+            n_ks += int(a[3] == "1" or a[4] == "1")
         if errs:
             bad += 1
             for e in errs:

@@ -15,7 +15,6 @@ b = torch.zeros(N, device=dev)
 y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
 st = hip.current_stream()
 os.environ["CODAE_GEMM_TILE"] = "q"
-os.environ["CODAE_GEMM_DBG8"] = "1"
 for d in ("0", "1", "2", "0", "1", "2"):
     os.environ["CODAE_GEMM_DBG"] = d
     hip.lib().codae_reload_env()

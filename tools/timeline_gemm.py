@@ -10,7 +10,6 @@ L = hip.lib()
 M, N = 8192, 1536
 dev = torch.device("cuda:0")
 os.environ["CODAE_GEMM_DBG"] = os.environ.get("TIMELINE_DBG", "8")   # 9: + no LDS-DMA, 10: + no MFMA (ablations)
-os.environ["CODAE_GEMM_DBG8"] = "1"
 hip.lib().codae_reload_env()
 g = torch.Generator(device="cpu").manual_seed(0)
 st = hip.current_stream()

@@ -7,7 +7,6 @@ sys.path.insert(0, os.path.join(ROOT, "mui-deepautoencoder_amd")); sys.path.inse
 import numpy as np
 import torch
 os.environ["CODAE_GEMM_DBG"] = "8"
-os.environ["CODAE_GEMM_DBG8"] = "1"
 from codae import hip
 from codae.train import HipEmbeddingTrainer
 import bench
