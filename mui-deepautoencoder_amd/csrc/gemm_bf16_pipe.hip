@@ -407,14 +407,14 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
             constexpr int CH = BN / 8, RL = NT / CH;
             const int c = threadIdx.x % CH, rl = threadIdx.x / CH;
             const int j = j0 + c * 8;
-            if (rl < RL && j < g.N) {
-                bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
-                for (int r = rl; r < BM; r += RL) {
-                    const int i = i0 + r;
-                    if (i >= g.M) break;
-                    const u32x4 lv = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(smem + r * PITCH + c * 16);
-                    *reinterpret_cast<uint4*>(Cb + (int64_t)i * g.ldc + j) = make_uint4(lv[0], lv[1], lv[2], lv[3]);
-                }
+            bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
+            constexpr int ITER = (BM + RL - 1) / RL;          // fully unrolled: every LDS read is issued before the first store
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int r = rl + it * RL;
+                const bool ok = rl < RL && j < g.N && r < BM && i0 + r < g.M;
+                const u32x4 lv = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(smem + (ok ? r : 0) * PITCH + c * 16);
+                if (ok) *reinterpret_cast<uint4*>(Cb + (int64_t)(i0 + r) * g.ldc + j) = make_uint4(lv[0], lv[1], lv[2], lv[3]);
             }
         }
         if constexpr (dbg_time) { wait_vmcnt<0>(); stamp(4); }
@@ -495,28 +495,51 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
         const int c = threadIdx.x % CH, rl = threadIdx.x / CH;
         const int j = j0 + c * 8;
         float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (rl < RL && j < g.N) {
+        {
+            // Fully unrolled with predicated stores and UNCONDITIONAL loads from clamped addresses: the ReLU-mask loads
+            // (the saved activation: 25 MB per launch, from HBM) of all of a thread's 12-13 rows are in flight together.
+            // As a loop with one row per trip every trip waited for its own load: the data-gradient launch was 10 us
+            // longer than the forward one.
             bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
-            for (int r = rl; r < BM; r += RL) {
-                const int i = i0 + r;
-                if (i >= g.M) break;
-                const u32x4 lv = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(smem + r * PITCH + c * 16);
-                uint4 v = make_uint4(lv[0], lv[1], lv[2], lv[3]);
-                if (EPI != 1 && g.relu_src != nullptr) {
-                    const uint4 h = *reinterpret_cast<const uint4*>(g.relu_src + (int64_t)i * g.ld_relu + j);
-                    auto keep = [](uint32_t val, uint32_t hh) -> uint32_t {
-                        const uint32_t lo = ((hh & 0x8000u) == 0 && (hh & 0x7fffu) != 0) ? 0x0000ffffu : 0u;
-                        const uint32_t hi = ((hh & 0x80000000u) == 0 && (hh & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
-                        return val & (lo | hi);
-                    };
-                    v.x = keep(v.x, h.x); v.y = keep(v.y, h.y); v.z = keep(v.z, h.z); v.w = keep(v.w, h.w);
+            constexpr int ITER = (BM + RL - 1) / RL;
+            const bool relu_mask = EPI != 1 && g.relu_src != nullptr;
+            const bf16_t* hsrc = relu_mask ? g.relu_src : g.A;                 // (no mask: any valid 16-B aligned bytes)
+            const int64_t hld = relu_mask ? g.ld_relu : 0;
+            const int jc = j < g.N ? j : 0;
+            uint4 hv[ITER];
+            if constexpr (EPI != 1) {
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) {
+                    const int r = rl + it * RL;
+                    const bool ok = rl < RL && j < g.N && r < BM && i0 + r < g.M;
+                    hv[it] = *reinterpret_cast<const uint4*>(hsrc + (int64_t)(ok ? i0 + r : 0) * hld + (relu_mask ? jc : 0));
                 }
-                *reinterpret_cast<uint4*>(Cb + (int64_t)i * g.ldc + j) = v;
-                if (EPI != 1 && g.colsum_part != nullptr) {
-                    cs[0] += bf16_to_f32((bf16_t)(v.x & 0xffff)); cs[1] += bf16_to_f32((bf16_t)(v.x >> 16));
-                    cs[2] += bf16_to_f32((bf16_t)(v.y & 0xffff)); cs[3] += bf16_to_f32((bf16_t)(v.y >> 16));
-                    cs[4] += bf16_to_f32((bf16_t)(v.z & 0xffff)); cs[5] += bf16_to_f32((bf16_t)(v.z >> 16));
-                    cs[6] += bf16_to_f32((bf16_t)(v.w & 0xffff)); cs[7] += bf16_to_f32((bf16_t)(v.w >> 16));
+            }
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int r = rl + it * RL;
+                const bool ok = rl < RL && j < g.N && r < BM && i0 + r < g.M;
+                const u32x4 lv = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(smem + (ok ? r : 0) * PITCH + c * 16);
+                uint4 v = make_uint4(lv[0], lv[1], lv[2], lv[3]);
+                if constexpr (EPI != 1) {
+                    if (relu_mask) {
+                        const uint4 h = hv[it];
+                        auto keep = [](uint32_t val, uint32_t hh) -> uint32_t {
+                            const uint32_t lo = ((hh & 0x8000u) == 0 && (hh & 0x7fffu) != 0) ? 0x0000ffffu : 0u;
+                            const uint32_t hi = ((hh & 0x80000000u) == 0 && (hh & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
+                            return val & (lo | hi);
+                        };
+                        v.x = keep(v.x, h.x); v.y = keep(v.y, h.y); v.z = keep(v.z, h.z); v.w = keep(v.w, h.w);
+                    }
+                }
+                if (ok) {
+                    *reinterpret_cast<uint4*>(Cb + (int64_t)(i0 + r) * g.ldc + j) = v;
+                    if (EPI != 1 && g.colsum_part != nullptr) {
+                        cs[0] += bf16_to_f32((bf16_t)(v.x & 0xffff)); cs[1] += bf16_to_f32((bf16_t)(v.x >> 16));
+                        cs[2] += bf16_to_f32((bf16_t)(v.y & 0xffff)); cs[3] += bf16_to_f32((bf16_t)(v.y >> 16));
+                        cs[4] += bf16_to_f32((bf16_t)(v.z & 0xffff)); cs[5] += bf16_to_f32((bf16_t)(v.z >> 16));
+                        cs[6] += bf16_to_f32((bf16_t)(v.w & 0xffff)); cs[7] += bf16_to_f32((bf16_t)(v.w >> 16));
+                    }
                 }
             }
         }
@@ -573,13 +596,13 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
                     }
                 }
             __syncthreads();
-            if (rl < RL && j < g.N) {
-                for (int r = rl; r < HR; r += RL) {
-                    const int i = i0 + hh * HR + r;
-                    if (i >= g.M) break;
-                    const f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(smem + r * PITCH + c * 16);
-                    *reinterpret_cast<float4*>(Cf + (int64_t)i * g.ldc + j) = make_float4(v[0], v[1], v[2], v[3]);
-                }
+            constexpr int ITER = (HR + RL - 1) / RL;
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int r = rl + it * RL;
+                const bool ok = rl < RL && j < g.N && r < HR && i0 + hh * HR + r < g.M;
+                const f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(smem + (ok ? r : 0) * PITCH + c * 16);
+                if (ok) *reinterpret_cast<float4*>(Cf + (int64_t)(i0 + hh * HR + r) * g.ldc + j) = make_float4(v[0], v[1], v[2], v[3]);
             }
             __syncthreads();
         }
