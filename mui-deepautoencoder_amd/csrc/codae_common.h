@@ -86,6 +86,7 @@ struct EnvToggles {
                                  // x = 256 x 192 pipelined, LDS-DMA on one wave per SIMD (6); -1 = automatic
     int gemm_dbg = 0;            // CODAE_GEMM_DBG timing-only ablation builds of the forward form
     int wgrad_splitk = 0;        // CODAE_WGRAD_SPLITK > 0 forces the split
+    int group_tile = -1;         // CODAE_GROUP_TILE: grouped weight gradients on 128 x 128 (0), 64 x 128 (1), 64 x 64 (2); -1 = automatic
     bool side_priority_set = false; int side_priority = 0;   // CODAE_SIDE_PRIORITY
     bool no_wt = false, single_stream = false, tail_on_side = false, no_fused_loss = false, flat_adam = false,
          no_fused_norm = false, no_chain = false;
@@ -144,6 +145,8 @@ struct GemmBf16 {
     int split_k;             // >1: fp32 partial slabs C + z*M*ldc, K range split evenly in BK units
     LossFuse loss;           // enabled: C receives dy (bf16), colsum_part the last bias gradient's partial sums
     int dbg;                 // timing-only ablations (CODAE_GEMM_DBG): 1 no LDS-DMA, 2 no MFMA, 4 no epilogue stores
+    double* sumsq_slots;     // fp32 output, 128 x 128 tile only: += sum of the stored values' squares, scattered over the
+                             // CODAE_S_N_SLOTS clip_grad_norm_ slots (what sumsq_kernel would add in a pass of its own), or null
 };
 bool gemm_bf16_supported(int M, int N, int K);
 int gemm_bf16_colsum_rows(const GemmBf16& g);   // rows of colsum_part this launch writes (= its tiles along M)
@@ -164,10 +167,11 @@ int gemm_bf16_grouped(GemmBf16Group& grp, hipStream_t s);
 // ---- persistent fused chain for narrow stacks (chain_bf16.hip) ----------------
 constexpr int CODAE_CHAIN_MAX_WIDTH = 512;
 constexpr int CODAE_CHAIN_MAX_LAYERS = 16;
+constexpr int CODAE_CHAIN_MAX_BIAS = 6144;          // floats: all layers' biases are staged in LDS
 struct ChainArgs {
     int L, rows, B;                                  // rows: batch padded to a multiple of 64
     int width[CODAE_CHAIN_MAX_LAYERS + 1];           // width[l] = input of layer l, width[L] = output of the last
-    uint8_t relu[CODAE_CHAIN_MAX_LAYERS];
+    uint32_t relu_flags;                             // bit l: layer l ends in a ReLU
     const bf16_t* W[CODAE_CHAIN_MAX_LAYERS];         // bf16 weight shadow   [out][in]
     const bf16_t* Wt[CODAE_CHAIN_MAX_LAYERS];        // transposed shadow    [in][out]
     const float* bias[CODAE_CHAIN_MAX_LAYERS];

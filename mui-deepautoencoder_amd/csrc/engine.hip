@@ -30,6 +30,7 @@ void env_reload() {
     }
     if (const char* d = getenv("CODAE_GEMM_DBG")) e.gemm_dbg = atoi(d);
     if (const char* k = getenv("CODAE_WGRAD_SPLITK")) e.wgrad_splitk = atoi(k) > 0 ? atoi(k) : 0;
+    if (const char* k = getenv("CODAE_GROUP_TILE")) e.group_tile = (k[0] >= '0' && k[0] <= '2') ? k[0] - '0' : -1;
     if (const char* pr = getenv("CODAE_SIDE_PRIORITY")) { e.side_priority_set = true; e.side_priority = atoi(pr); }
     e.no_wt = getenv("CODAE_NO_WT") != nullptr;
     e.single_stream = getenv("CODAE_SINGLE_STREAM") != nullptr;
@@ -238,7 +239,7 @@ int run_chain(const codae_engine* e, const codae_buffers* b, const codae_batch* 
     a.L = L; a.rows = rows; a.B = B;
     for (int l = 0; l < L; ++l) {
         a.width[l] = e->in[l];
-        a.relu[l] = e->relu[l];
+        if (e->relu[l]) a.relu_flags |= 1u << l;
         a.W[l] = reinterpret_cast<const bf16_t*>(b->shadow_w) + e->w_off[l];
         a.Wt[l] = reinterpret_cast<const bf16_t*>(b->shadow_wt) + e->w_off[l];
         a.bias[l] = b->params + e->b_off[l];
@@ -268,7 +269,8 @@ int run_chain(const codae_engine* e, const codae_buffers* b, const codae_batch* 
 }
 
 // every layer's weight gradient dW_l = dA_l^T H_l in one grouped launch (fp32 straight into grads: no split-K slabs)
-int run_wgrad_grouped(const codae_engine* e, const codae_buffers* b, int rows, hipStream_t s) {
+// with_norm: each tile also adds its sum g^2 to the clip_grad_norm_ slots (no separate pass over the gradients)
+int run_wgrad_grouped(const codae_engine* e, const codae_buffers* b, int rows, bool with_norm, hipStream_t s) {
     for (int base = 0; base < e->L; base += CODAE_GROUP_MAX) {
         GemmBf16Group grp{};
         grp.n = 0;
@@ -278,6 +280,7 @@ int run_wgrad_grouped(const codae_engine* e, const codae_buffers* b, int rows, h
             g.B = reinterpret_cast<const bf16_t*>(act_ptr(e, b, l)); g.ldb = e->in[l]; g.b_mode = OP_KS;
             g.C = b->grads + e->w_off[l]; g.ldc = e->in[l]; g.c_f32 = 1;
             g.M = e->out[l]; g.N = e->in[l]; g.K = rows; g.split_k = 1;
+            g.sumsq_slots = with_norm ? b->scalars + CODAE_S_GRAD_SQ_SLOTS : nullptr;
         }
         ProfScope prof(e, CODAE_K_GEMM_WGRAD, s);
         int rc = gemm_bf16_grouped(grp, s);
@@ -966,11 +969,12 @@ int codae_train_step(codae_handle h, const codae_buffers* b, const codae_batch* 
         if (rcc) return rcc;
         rcc = run_chain(h, b, batch, hyper, true, s);
         if (rcc) return rcc;
-        rcc = run_wgrad_grouped(h, b, h->rows_for(batch->B), s);
+        const bool with_norm = hyper->max_grad_norm > 0.f && !h->cfg.no_fused_norm;     // (finish_loss zeroed the norm slots)
+        rcc = run_wgrad_grouped(h, b, h->rows_for(batch->B), with_norm, s);
         if (rcc) return rcc;
-        rcc = finish_bias(h, b, s, false);
+        rcc = finish_bias(h, b, s, with_norm);
         if (rcc) return rcc;
-        return update_impl(h, b, hyper, s, false);
+        return update_impl(h, b, hyper, s, with_norm);
     }
     int rc = codae_step_forward_loss(h, b, batch, hyper, nullptr, stream);
     if (rc) return rc;

@@ -46,6 +46,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, lds_char* dst_wave_base
 // A 32-lane half of one ds_read_b64_tr_b16 touches 8 k-rows (kr = 8g + q [+4], g&1 in {0,1},
 // q in 0..3) x one 32-B block; the 8 reads must fall on 8 different 32-B slots of the 256-B bank row.
 //   R = 128 / 256 (row = 1 or 2 bank rows): block' = block ^ key,  key = q | ((g & 1) << 2)
+//   R = 64 (row = half a bank row, 4 blocks: the row's parity picks the half): key = ((kr >> 1) & 1) | (((kr >> 3) & 1) << 1)
 //   R = 192 (row = 1.5 bank rows, 12 blocks): slot = (4 kr + block') mod 8, so rotate:
 //            block' = (block + rot) mod 12, rot = ((kr >> 1) & 1) + 2 ((kr >> 3) & 1)
 template <int R>
@@ -53,7 +54,10 @@ __device__ __forceinline__ int ks_to_lds_block(int block, int kr) {
     if constexpr (R == 192) {
         const int b = block + ((kr >> 1) & 1) + 2 * ((kr >> 3) & 1);
         return b >= 12 ? b - 12 : b;
+    } else if constexpr (R == 64) {
+        return block ^ (((kr >> 1) & 1) | (((kr >> 3) & 1) << 1));
     } else {
+        static_assert(R == 128 || R == 256, "KS image: 64, 128, 192 or 256 columns");
         return block ^ ((kr & 3) | (((kr >> 3) & 1) << 2));
     }
 }
@@ -62,6 +66,8 @@ __device__ __forceinline__ int ks_from_lds_block(int lds_block, int kr) {
     if constexpr (R == 192) {
         const int b = lds_block - ((kr >> 1) & 1) - 2 * ((kr >> 3) & 1);
         return b < 0 ? b + 12 : b;
+    } else if constexpr (R == 64) {
+        return lds_block ^ (((kr >> 1) & 1) | (((kr >> 3) & 1) << 1));
     } else {
         return lds_block ^ ((kr & 3) | (((kr >> 3) & 1) << 2));
     }
@@ -461,6 +467,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmBf16& g, int tiles_n, i
         if (g.split_k > 1) Cf += (int64_t)z * g.M * g.ldc;
         const int c = threadIdx.x % CH, rl = threadIdx.x / CH;
         const int j = j0 + c * 4;
+        float sq = 0.f;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             if (((BM / WM) * wr) / HR == hh) {
@@ -487,9 +494,22 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmBf16& g, int tiles_n, i
                     if (i >= g.M) break;
                     const f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(smem + r * PITCH + c * 16);
                     *reinterpret_cast<float4*>(Cf + (int64_t)i * g.ldc + j) = make_float4(v[0], v[1], v[2], v[3]);
+                    sq += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
                 }
             }
             __syncthreads();
+        }
+        if (g.sumsq_slots != nullptr) {                  // clip_grad_norm_'s sum g^2 over this tile (grouped weight gradients)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+            float* red = reinterpret_cast<float*>(smem_raw);
+            if (lane == 0) red[w] = sq;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float t = 0.f;
+                for (int ww = 0; ww < NW; ++ww) t += red[ww];
+                atomicAdd(g.sumsq_slots + (blockIdx.x & (CODAE_S_N_SLOTS - 1)), (double)t);
+            }
         }
     }
 }
@@ -505,14 +525,15 @@ void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
 
 // Several weight-gradient GEMMs (k-strided operands, fp32 output) in one launch: workgroup -> (GEMM, tile) by the prefix
 // sums in the descriptor block.  128 x 128 tiles: the narrow stacks this exists for have 9-16 tiles per layer.
+template <int BM, int BN>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_grouped_kernel(GemmBf16Group grp) {
-    __shared__ __attribute__((aligned(16))) char smem_raw[2 * (128 + 128) * 128];
+    __shared__ __attribute__((aligned(16))) char smem_raw[2 * (BM + BN) * 128];
     int j = 0;
     while (j + 1 < grp.n && (int)blockIdx.x >= grp.wg_begin[j + 1]) ++j;
     const GemmBf16& g = grp.g[j];
-    const int tiles_m = (g.M + 127) / 128, tiles_n = (g.N + 127) / 128;
-    gemm_bf16_tile<128, 128, 2, 2, OP_KS, OP_KS, true, false>(g, tiles_n, tiles_m * tiles_n, g.K / BK, blockIdx.x - grp.wg_begin[j],
-                                                              grp.wg_begin[j + 1] - grp.wg_begin[j], smem_raw);
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    gemm_bf16_tile<BM, BN, 2, 2, OP_KS, OP_KS, true, false>(g, tiles_n, tiles_m * tiles_n, g.K / BK, blockIdx.x - grp.wg_begin[j],
+                                                            grp.wg_begin[j + 1] - grp.wg_begin[j], smem_raw);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -538,20 +559,31 @@ int launch_cfg(const GemmBf16& g, hipStream_t s) {
 
 }  // namespace
 
+// Tile of the grouped launch: 128 x 128 when that alone gives every CU a workgroup, else 64 x 128, else 64 x 64 (C2's ten
+// 384 x 384 weight gradients: 90 / 180 / 360 workgroups).
 int gemm_bf16_grouped(GemmBf16Group& grp, hipStream_t s) {
     CODAE_REQUIRE(grp.n >= 1 && grp.n <= CODAE_GROUP_MAX, "gemm_bf16_grouped: %d GEMMs", grp.n);
-    int total = 0;
+    auto count = [&](int bm, int bn) {
+        int total = 0;
+        for (int j = 0; j < grp.n; ++j) {
+            const GemmBf16& g = grp.g[j];
+            grp.wg_begin[j] = total;
+            total += ((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * g.split_k;
+        }
+        grp.wg_begin[grp.n] = total;
+        return total;
+    };
     for (int j = 0; j < grp.n; ++j) {
         const GemmBf16& g = grp.g[j];
         CODAE_REQUIRE(g.a_mode == OP_KS && g.b_mode == OP_KS && g.c_f32 && g.split_k >= 1 && g.K % BK == 0 && g.K >= BK && g.M % 8 == 0 &&
                           g.N % 8 == 0 && !g.loss.enabled && g.relu_src == nullptr && g.colsum_part == nullptr && g.bias == nullptr,
                       "gemm_bf16_grouped: GEMM %d is not a plain weight-gradient form", j);
-        CODAE_REQUIRE(g.split_k <= g.K / BK, "gemm_bf16_grouped: split_k %d > k tiles", g.split_k);
-        grp.wg_begin[j] = total;
-        total += ((g.M + 127) / 128) * ((g.N + 127) / 128) * g.split_k;
     }
-    grp.wg_begin[grp.n] = total;
-    hipLaunchKernelGGL(gemm_bf16_grouped_kernel, dim3(total), dim3(256), 0, s, grp);
+    int tile = env().group_tile;
+    if (tile < 0) tile = count(128, 128) >= 256 ? 0 : (count(64, 128) >= 256 ? 1 : 2);
+    if (tile == 0) { const int total = count(128, 128); hipLaunchKernelGGL((gemm_bf16_grouped_kernel<128, 128>), dim3(total), dim3(256), 0, s, grp); }
+    else if (tile == 1) { const int total = count(64, 128); hipLaunchKernelGGL((gemm_bf16_grouped_kernel<64, 128>), dim3(total), dim3(256), 0, s, grp); }
+    else { const int total = count(64, 64); hipLaunchKernelGGL((gemm_bf16_grouped_kernel<64, 64>), dim3(total), dim3(256), 0, s, grp); }
     CODAE_LAUNCH_CHECK();
     return CODAE_OK;
 }

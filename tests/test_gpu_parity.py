@@ -366,14 +366,21 @@ def test_fused_f32_vs_oracle_3x128_batch1024():
         assert close(tr.engine.bias(l).cpu().numpy(), b)
 
 
-def test_chain_step_equals_per_layer_step(monkeypatch):
-    """The persistent fused chain against the per-layer launches on BASELINE config C2's shape (3 x 128, batch 1024; and a
+@pytest.mark.parametrize("group_tile", ["auto", "0", "1", "2"])
+def test_chain_step_equals_per_layer_step(monkeypatch, group_tile):
+    """(group_tile: the grouped weight-gradient launch on its automatic tile, then forced to 128 x 128, 64 x 128, 64 x 64;
+    the norm's sum g^2 comes from that launch's epilogue, scalars[2] below.)  The persistent fused chain against the per-layer launches on BASELINE config C2's shape (3 x 128, batch 1024; and a
     ragged batch of a tapered stack): both run the same MFMA instruction over the same k order, so every saved
     activation and every activation gradient must agree BIT FOR BIT (the whole workspaces are compared); weight
     gradients differ only by fp32 summation order (the per-layer path splits the batch reduction 8 ways, the grouped
     launch does not), bias gradients and the loss by how many rows a partial sum spans (16 vs 128)."""
     from codae.hip.engine import DaeEngine
+    from codae import hip
     from oracle import dae_oracle as O
+    if group_tile == "auto":
+        monkeypatch.delenv("CODAE_GROUP_TILE", raising=False)
+    else:
+        monkeypatch.setenv("CODAE_GROUP_TILE", group_tile)
     for (S, E, z, nl, B) in ((3, 128, 384, 4, 1024), (3, 64, 64, 2, 333)):
         io = S * E
         rng = np.random.default_rng(B)
