@@ -7,17 +7,25 @@
 //
 // Decomposition: rows.  A workgroup (4 waves) owns 16 batch rows and walks them through every layer; nothing is ever
 // exchanged between workgroups, so there is no grid barrier and no cross-workgroup visibility protocol.  The 16 x width
-// activation panel lives in LDS (two ping-pong buffers), the weights are never staged: each wave owns a quarter of the
-// layer's output columns and streams its weight fragments straight from L2 into registers (a narrow stack's bf16
-// weights - 2.9 MB at 10 x 384^2 - sit in every XCD's 4 MiB L2), since no other wave of the workgroup would read the
-// same fragment.  v_mfma_f32_16x16x32_bf16 with swapped operands, as in the big GEMM kernels: a lane ends up with 4
-// consecutive output columns of one row.  Per layer the panel's result goes to the other LDS buffer (input of the
-// next layer) and, in whole rows, to HBM: the weight-gradient GEMMs (one grouped launch afterwards) need H_l and dA_l.
-// The data-gradient chain is the same loop over the TRANSPOSED weight shadow with the ReLU mask taken from the saved
-// activation and the column sums of dA (bias gradient) written as one partial row per workgroup.
+// activation panel lives in LDS (two ping-pong buffers).  Each wave owns a quarter of every layer's output columns; no
+// other wave of the workgroup reads the same weights, so each wave streams them through a PRIVATE LDS ring filled by
+// LDS-DMA, running ahead of the multiply across layer boundaries (see "the weight stream" below).  v_mfma_f32_16x16x32_bf16
+// with swapped operands, as in the big GEMM kernels: a lane ends up with 4 consecutive output columns of one row.  Per
+// layer the panel's result goes to the other LDS buffer (input of the next layer) and, in whole rows, to HBM: the
+// weight-gradient GEMMs (one grouped launch afterwards) need H_l and dA_l.  The data-gradient chain is the same loop over
+// the TRANSPOSED weight shadow; the ReLU mask of each activation is kept from the forward pass as 4 bits per tile and
+// thread in LDS (the same thread owns the same (row, columns) of dA_l), the column sums of dA (bias gradient) are
+// written as one partial row per workgroup.  Biases are staged in LDS once: inside the layer loops the only vector
+// memory operations are the ring's requests and plain stores, so nothing ever has to wait for the ring to drain.
 //
-// What bounds it: every workgroup streams all weights once per direction (C2: 2 x 2.9 MB per workgroup, 64 workgroups),
-// i.e. the per-CU L2 -> register rate, not MFMA (72 MFMAs per wave and layer) and not HBM.
+// What bounds it (C2, tools/chain_timeline.py on the CHAIN_ABL=9 build): 3.6 us per 384 x 384 matrix and workgroup,
+// whatever the ring depth (10, 12, 13 units measured the same) - a CU takes its weights at ~81 GB/s: every byte is
+// written to LDS by the DMA and read back once as a fragment (without the reads: 3.1 us, 96 GB/s; without requests at
+// all: 1.5 us).  Epilogues 1.3 us per layer, prologue 8 us, 108 us in all; 64 of the 256 CUs are busy.  Not MFMA (72
+// per wave and layer), not HBM (the weights stay in L2).  Negative results kept out of the code: an extra wave per
+// workgroup that touched the next matrix's lines ahead of the rings (L2 warmer: 133 -> 130 us, within noise once the
+// rings existed), and rotating which columns each workgroup starts with so that the workgroups of an XCD do not ask for
+// the same lines at the same time (slower: 3.6 -> 3.9 us per matrix; L2 serves the lockstep requests better).
 #include "codae_common.h"
 
 #ifndef CHAIN_ABL

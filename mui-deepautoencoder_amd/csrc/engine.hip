@@ -225,7 +225,10 @@ int finish_bias(const codae_engine* e, const codae_buffers* b, hipStream_t s, bo
     return launch_bias_finish(jobs, with_norm ? b->scalars + CODAE_S_GRAD_SQ : nullptr, s);
 }
 
-constexpr int CHAIN_MAX_ROWS = 8192;      // beyond this the per-layer GEMMs (weights read once per 256 rows) win
+// Every 16 rows stream all the weights from L2.  Up to 128 workgroups (16 per XCD) that costs nothing extra per row: 3 x 128
+// stack, ms / step chain vs per-layer: 1024 rows 0.158 / 0.31, 2048 rows 0.161 / 0.31.  With every CU streaming (4096 rows:
+// 0.83 / 0.34, 8192: 1.71 / 0.40) the XCDs' L2s cannot feed them and the per-layer GEMMs (weights read once per 256 rows) win.
+constexpr int CHAIN_MAX_ROWS = 2048;
 
 bool chain_eligible(const codae_engine* e, const codae_buffers* b, int B) {
     return e->chain_ok && b->shadow_wt != nullptr && e->rows_for(B) <= CHAIN_MAX_ROWS;
