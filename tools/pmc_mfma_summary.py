@@ -46,6 +46,8 @@ for d, c in rows.items():
 fl = 2.0 * M * N * K
 print("%-14s %6s %9s %8s %10s %10s %9s" % ("class", "n", "avg us", "GHz", "MFMA busy", "CU busy", "TFLOP/s"))
 for cls, v in sorted(agg.items()):
+    med = sorted(x[0] for x in v)[len(v) // 2]
+    v = [x for x in v if x[0] <= 3 * med]          # (the first dispatch of a kernel carries its code-object load: 917 us once)
     n = len(v)
     dur = sum(x[0] for x in v) / n / 1e3
     print("%-14s %6d %9.1f %8.2f %9.1f%% %9.1f%% %9s" % (cls, n, dur, sum(x[1] for x in v) / n, 100 * sum(x[2] for x in v) / n, 100 * sum(x[3] for x in v) / n,
