@@ -37,9 +37,10 @@ extern "C" {
  *   2: codae_buffers.shadow_wt, CODAE_S_ADAM_STEP / CODAE_S_COUNT 80, codae_struct_sizes, codae_reload_env,
  *      codae_train_step_graph, codae_step_backward_async, codae_side_stream, codae_join, codae_profile_stride
  *   3: codae_chain_*, CODAE_K_* additions, codae_reduce_* (this round; see the entries' comments)
+ *   4: + codae_ranking_loss_batched, codae_gather_inventory_rows (new entries only; no layout change)
  * The binding must refuse a library whose codae_abi_version() differs and must check its own struct sizes against
  * codae_struct_sizes() at load (mui-deepautoencoder_amd/codae/hip/__init__.py does both). */
-#define CODAE_ABI_VERSION 3
+#define CODAE_ABI_VERSION 4
 
 enum {
     CODAE_OK = 0,
@@ -297,6 +298,22 @@ int codae_row_norms(const float* m, int64_t rows, int32_t E, float* out, void* s
 int codae_ranking_loss(const float* pred, const float* fmask, const int32_t* idx, int32_t B, int32_t io, int32_t n_slots,
                        int32_t E, const float* inventory, const float* inventory_norm, int64_t n_obs, const int32_t* val_idx,
                        int32_t n_val, double* out, void* stream);
+
+/* RankingLoss.get for a whole validation batch as GEMMs (metering.py:46-79), nothing through the host:
+ * blanked slot of sample b from mask_table[id_b] with id_b = mask_id[b] or mask_to_use[row_idx[b] * nb_run + run] (the
+ * Corrupter's device tables, as codae_batch); similarities pred[:, slot] . inv_val^T by the exact-fp32 MFMA GEMM, chunk
+ * validation rows at a time; *out += sum_b 1 - rank_b / (n_val - 1) (accumulates over the batches of an epoch).
+ * inv_val [n_slots][n_val][E] = codae_gather_inventory_rows(inventory, val_idx), inv_val_norm its row norms;
+ * val_pos [n_obs]: position of an observation in val_idx or -1 (a sample's own validation row is never counted: the
+ * reference compares s[idx] with itself there), may be NULL; work: B * chunk floats; row_state: 32 * B bytes. */
+int codae_ranking_loss_batched(const float* pred, int32_t B, int32_t io, int32_t n_slots, int32_t E, const int32_t* row_idx,
+                               const int32_t* mask_id, const int32_t* mask_to_use, int32_t nb_run, int32_t run,
+                               const uint8_t* mask_table, const float* inventory, const float* inventory_norm, int64_t n_obs,
+                               const float* inv_val, const float* inv_val_norm, const int32_t* val_pos, int32_t n_val, float* work,
+                               int32_t chunk, void* row_state, double* out, void* stream);
+/* dst[c][j][:] = inventory[c][val_idx[j]][:]  (inventory [n_slots][n_obs][E]) */
+int codae_gather_inventory_rows(const float* inventory, int64_t n_obs, int32_t E, int32_t n_slots, const int32_t* val_idx,
+                                int32_t n_val, float* dst, void* stream);
 
 /* ---- GEMM primitives (exported for kernel-level parity tests / benchmarks) - */
 /* y[M][N] = act(x[M][K] . W[N][K]^T + b[N]), fp32, exact-fp32 MFMA */

@@ -45,9 +45,8 @@ class RankingLoss:
         self.validation_indices = validation_indices
         self._val = None
 
-    def _get_hip(self, prediction, fmask, indices):
+    def _get_inventory(self, dev):
         ds = self.dataset
-        dev = prediction.device
         S, E = ds.nb_used_category, ds.embedding_size
         if getattr(self, "_inv", None) is None or self._inv.device != dev:
             self._inv = torch.stack([ds.data_per_category[c].to(dev, torch.float32) for c in range(S)]).contiguous()
@@ -56,6 +55,12 @@ class RankingLoss:
                 _check(_hip_lib().codae_row_norms(_ptr(self._inv), S * self._inv.shape[1], E, _ptr(self._inv_norm), _stream()))
             self._val_i32 = torch.as_tensor(list(self.validation_indices), dtype=torch.int32, device=dev)
             self._out = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    def _get_hip(self, prediction, fmask, indices):
+        ds = self.dataset
+        dev = prediction.device
+        S, E = ds.nb_used_category, ds.embedding_size
+        self._get_inventory(dev)
         idx = torch.as_tensor(list(indices), dtype=torch.int32, device=dev)
         pred = prediction.detach().to(torch.float32).contiguous()
         fm = fmask.to(device=dev, dtype=torch.float32).contiguous()
@@ -66,6 +71,56 @@ class RankingLoss:
                                                  _ptr(self._val_i32), len(self.validation_indices), _ptr(self._out),
                                                  _stream()))
         return float(self._out.item())
+
+    # ---- device-resident form: one batched call per validation batch, one read-back per epoch ---------
+    def _device_tables(self, dev):
+        self._get_inventory(dev)
+        if getattr(self, "_inv_val", None) is None or self._inv_val.device != dev:
+            S, E = self.dataset.nb_used_category, self.dataset.embedding_size
+            V = len(self.validation_indices)
+            self._inv_val = torch.empty((S, V, E), dtype=torch.float32, device=dev)
+            self._inv_val_norm = torch.empty((S, V), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _check(_hip_lib().codae_gather_inventory_rows(_ptr(self._inv), self._inv.shape[1], E, S, _ptr(self._val_i32), V,
+                                                              _ptr(self._inv_val), _stream()))
+                _check(_hip_lib().codae_row_norms(_ptr(self._inv_val), S * V, E, _ptr(self._inv_val_norm), _stream()))
+            pos = torch.full((self._inv.shape[1],), -1, dtype=torch.int32)
+            pos[torch.as_tensor(list(self.validation_indices), dtype=torch.long)] = torch.arange(V, dtype=torch.int32)
+            self._val_pos = pos.to(dev)
+            self._acc = torch.zeros(1, dtype=torch.float64, device=dev)
+            self._work = None
+
+    def add(self, prediction, row_idx, corrupter, run=0, chunk=4096):
+        """Accumulate RankingLoss.get(prediction, fmask, indices) of one validation batch ON THE DEVICE: `row_idx` int32
+        dataset rows (device), masks taken from `corrupter`'s device tables for `run`.  No host synchronisation; read the
+        epoch's sum with total()."""
+        dev = prediction.device
+        self._device_tables(dev)
+        S, E = self.dataset.nb_used_category, self.dataset.embedding_size
+        V = len(self.validation_indices)
+        pred = prediction.detach()
+        if pred.dtype != torch.float32 or not pred.is_contiguous():
+            pred = pred.to(torch.float32).contiguous()
+        B = pred.shape[0]
+        chunk = min(int(chunk), V)
+        if self._work is None or self._work.numel() < B * chunk or self._rows.numel() < 8 * B:
+            self._work = torch.empty(B * chunk, dtype=torch.float32, device=dev)
+            self._rows = torch.empty(8 * B, dtype=torch.int32, device=dev)
+        m2u = corrupter.mask_to_use_i32
+        with torch.cuda.device(dev):
+            _check(_hip_lib().codae_ranking_loss_batched(
+                _ptr(pred), B, pred.shape[1], S, E, _ptr(row_idx), None, _ptr(m2u), m2u.shape[1], int(run),
+                _ptr(corrupter.mask_table_u8), _ptr(self._inv), _ptr(self._inv_norm), self._inv.shape[1],
+                _ptr(self._inv_val), _ptr(self._inv_val_norm), _ptr(self._val_pos), V, _ptr(self._work), chunk, _ptr(self._rows), _ptr(self._acc),
+                _stream()))
+        self._keep = (pred, row_idx)             # (alive until the stream has consumed them)
+
+    def total(self, reset=True):
+        """Sum of the batches add()ed since the last reset (one device-to-host read)."""
+        v = float(self._acc.item())
+        if reset:
+            self._acc.zero_()
+        return v
 
     def get(self, prediction, fmask, indices):
         if prediction.device.type == "cuda":

@@ -170,6 +170,90 @@ __global__ __launch_bounds__(NT) void ranking_kernel(const float* __restrict__ p
     }
 }
 
+
+// ---- RankingLoss as a GEMM --------------------------------------------------------------------------
+// The wave-per-item kernel above reads the whole validation inventory once PER SAMPLE (V x E floats: 53 MB at C3's
+// shape, 1.4 TB per validation epoch - 20x the training epoch).  Here the similarities of a whole batch against a chunk
+// of the validation inventory are one exact-fp32 MFMA GEMM per slot (gemm_f32.hip: pred[:, cE:(c+1)E] . inv_val_c^T),
+// followed by a compare-count pass; the batch's mask ids come from the Corrupter's device tables, nothing goes
+// through the host, and *out accumulates over the batches of an epoch.
+//   rs[b] = {slot c, |q| clamped, own similarity, rank so far}
+struct RankRow { int slot; float qn; float own; int rank; int self_col; int pad[3]; };
+
+// one wave per sample: blanked slot from the mask table (metering.py:56: sum of the blanked slots' indices), |q|, s[idx_b]
+__global__ __launch_bounds__(NT) void rank_prep_kernel(const float* __restrict__ pred, const int32_t* __restrict__ row_idx,
+                                                       const int32_t* __restrict__ mask_id, const int32_t* __restrict__ mask_to_use,
+                                                       int nb_run, int run, const uint8_t* __restrict__ mask_table, int B, int io, int S,
+                                                       int E, const float* __restrict__ inv, const float* __restrict__ inv_norm,
+                                                       int64_t n_obs, const int32_t* __restrict__ val_pos, RankRow* __restrict__ rs) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int64_t me = row_idx[b];
+    const int id = mask_id ? mask_id[b] : mask_to_use[me * nb_run + run];
+    int c = 0;
+    for (int s = 1; s < S; ++s) c += (mask_table[(int64_t)id * io + (int64_t)s * E] == 0) ? s : 0;
+    c = c < S ? c : S - 1;                       // (k > 1 blanks several slots; the reference's formula is meant for k = 1)
+    const float* q = pred + (int64_t)b * io + (int64_t)c * E;
+    const float* r = inv + ((int64_t)c * n_obs + me) * E;
+    float sq = 0.f, d = 0.f;
+    for (int k = lane; k < E; k += 64) { const float v = q[k]; sq += v * v; d += v * r[k]; }
+    sq = wave_sum_f(sq); d = wave_sum_f(d);
+    if (lane == 0) {
+        const float qn = fmaxf(sqrtf(sq), 1e-8f);
+        RankRow o; o.slot = c; o.qn = qn; o.own = d / (qn * fmaxf(inv_norm[(int64_t)c * n_obs + me], 1e-8f)); o.rank = 0;
+        // The sample's own row, when it is a validation row, is never counted by the reference: s[idx] > s[idx] compares a
+        // value with itself.  Here `own` and the GEMM's column for that row are summed in different orders, so that
+        // column is skipped by position instead.
+        o.self_col = val_pos ? val_pos[me] : -1;
+        o.pad[0] = o.pad[1] = o.pad[2] = 0;
+        rs[b] = o;
+    }
+}
+
+// rows whose blanked slot is c: rank += #{ j < n : own > dots[b][j] / (|q| |inv_j|) }; one wave per row
+__global__ __launch_bounds__(NT) void rank_count_kernel(const float* __restrict__ dots, int64_t ld, int B, int n, int c, int v0,
+                                                        const float* __restrict__ val_norm, RankRow* __restrict__ rs) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const RankRow me = rs[b];
+    if (me.slot != c) return;
+    const float* d = dots + (int64_t)b * ld;
+    int cnt = 0;
+    const int skip = me.self_col - v0;
+    for (int j = lane; j < n; j += 64) cnt += (j != skip && me.own > d[j] / (me.qn * fmaxf(val_norm[j], 1e-8f))) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0) rs[b].rank = me.rank + cnt;
+}
+
+// *out += sum_b 1 - rank_b / (V - 1), rows added in index order (one workgroup: the same bits every run)
+__global__ __launch_bounds__(NT) void rank_finish_kernel(const RankRow* __restrict__ rs, int B, int V, double* __restrict__ out) {
+    __shared__ double red[NT];
+    double t = 0.0;
+    for (int b = threadIdx.x; b < B; b += NT) t += 1.0 - (double)rs[b].rank / (double)(V - 1);
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = NT / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out += red[0];
+}
+
+// rows val[j] of every slot's inventory, contiguous: dst[c][j][:] = inv[c][val[j]][:]
+__global__ __launch_bounds__(NT) void gather_rows_kernel(const float* __restrict__ inv, int64_t n_obs, int E, int S,
+                                                         const int32_t* __restrict__ val, int V, float* __restrict__ dst) {
+    const int64_t total = (int64_t)S * V * E;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < total; e += (int64_t)gridDim.x * NT) {
+        const int k = (int)(e % E);
+        const int64_t cj = e / E;
+        const int j = (int)(cj % V), c = (int)(cj / V);
+        dst[e] = inv[((int64_t)c * n_obs + val[j]) * E + k];
+    }
+}
+
 inline int grid_for(int64_t items) {
     int64_t b = (items + NT - 1) / NT;
     if (b < 1) b = 1;
@@ -226,6 +310,49 @@ int codae_ranking_loss(const float* pred, const float* fmask, const int32_t* idx
     CODAE_REQUIRE((size_t)E * sizeof(float) <= 64 * 1024, "ranking_loss: embedding size %d too large for LDS staging", E);
     hipLaunchKernelGGL(ranking_kernel, dim3(B), dim3(NT), (size_t)E * sizeof(float), (hipStream_t)stream, pred, fmask, idx, io,
                        n_slots, E, inventory, inventory_norm, n_obs, val_idx, n_val, out);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+int codae_gather_inventory_rows(const float* inventory, int64_t n_obs, int32_t E, int32_t n_slots, const int32_t* val_idx,
+                                int32_t n_val, float* dst, void* stream) {
+    CODAE_REQUIRE(inventory && val_idx && dst && n_obs > 0 && E > 0 && n_slots > 0 && n_val > 0, "gather_inventory_rows: bad argument");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((int64_t)n_slots * n_val * E)), dim3(NT), 0, (hipStream_t)stream, inventory,
+                       n_obs, E, n_slots, val_idx, n_val, dst);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+int codae_ranking_loss_batched(const float* pred, int32_t B, int32_t io, int32_t n_slots, int32_t E, const int32_t* row_idx,
+                               const int32_t* mask_id, const int32_t* mask_to_use, int32_t nb_run, int32_t run,
+                               const uint8_t* mask_table, const float* inventory, const float* inventory_norm, int64_t n_obs,
+                               const float* inv_val, const float* inv_val_norm, const int32_t* val_pos, int32_t n_val, float* work,
+                               int32_t chunk, void* row_state, double* out, void* stream) {
+    CODAE_REQUIRE(pred && row_idx && (mask_id || mask_to_use) && mask_table && inventory && inventory_norm && inv_val && inv_val_norm &&
+                      work && row_state && out, "ranking_loss_batched: null argument");
+    CODAE_REQUIRE(B > 0 && n_slots > 0 && E > 0 && io == n_slots * E && n_val > 1 && n_obs > 0 && chunk > 0, "ranking_loss_batched: bad sizes");
+    CODAE_REQUIRE(mask_id || (nb_run > 0 && run >= 0 && run < nb_run), "ranking_loss_batched: run %d outside [0, %d)", run, nb_run);
+    hipStream_t s = (hipStream_t)stream;
+    RankRow* rs = reinterpret_cast<RankRow*>(row_state);
+    const int rows_grid = (B + NT / 64 - 1) / (NT / 64);
+    hipLaunchKernelGGL(rank_prep_kernel, dim3(rows_grid), dim3(NT), 0, s, pred, row_idx, mask_id, mask_to_use, nb_run, run, mask_table, B,
+                       io, n_slots, E, inventory, inventory_norm, n_obs, val_pos, rs);
+    CODAE_LAUNCH_CHECK();
+    for (int c = 0; c < n_slots; ++c)
+        for (int v0 = 0; v0 < n_val; v0 += chunk) {
+            const int n = n_val - v0 < chunk ? n_val - v0 : chunk;
+            GemmF32 g{};
+            g.A = pred + (int64_t)c * E; g.a_rs = io; g.a_ks = 1;
+            g.B = inv_val + ((int64_t)c * n_val + v0) * E; g.b_rs = E; g.b_ks = 1;
+            g.C = work; g.ldc = chunk;
+            g.M = B; g.N = n; g.K = E;
+            int rc = gemm_f32(g, s);
+            if (rc) return rc;
+            hipLaunchKernelGGL(rank_count_kernel, dim3(rows_grid), dim3(NT), 0, s, work, (int64_t)chunk, B, n, c, v0,
+                               inv_val_norm + (int64_t)c * n_val + v0, rs);
+            CODAE_LAUNCH_CHECK();
+        }
+    hipLaunchKernelGGL(rank_finish_kernel, dim3(1), dim3(NT), 0, s, rs, B, n_val, out);
     CODAE_LAUNCH_CHECK();
     return CODAE_OK;
 }

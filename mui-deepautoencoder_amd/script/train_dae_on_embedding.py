@@ -130,12 +130,14 @@ def main():
         log.info("TRAINING FULL ERROR      = %7f" % book["ftl"][-1])
         log.info("TRAINING PARTIAL ERROR   = %7f" % book["ptl"][-1])
 
-        rl = 0.0
+        # validation (reference :241-261) stays on the device: forward + metric sums in the engine, the rank metric as
+        # batched GEMMs against the validation inventory with the masks taken from the Corrupter's device tables; one
+        # read-back per epoch instead of a mask expansion, two .tolist() and a host sync per batch
         for batch_indices in validation_sampler:
             idx = batch_indices.to(device=device, dtype=torch.int32)
             y = trainer.eval_batch(idx, run=0, want_y=True)
-            _, fmask = corrupter.get_masks(batch_indices.tolist(), 0)
-            rl += ranking_loss.get(y, fmask, batch_indices.tolist())
+            ranking_loss.add(y, idx, corrupter, run=0)
+        rl = ranking_loss.total()
         sq, sqp = trainer.epoch_sums(reduce=False)      # every rank evaluates the whole validation set
         book["fvl"].append(np.sqrt(sq / (dataset.nb_predictor * nb_validation)))
         book["pvl"].append(np.sqrt(sqp / (nb_validation * dataset.nb_predictor / S)))

@@ -359,6 +359,64 @@ def test_ranking_loss_kernel_matches_oracle():
 
 
 @pytest.mark.gpu
+def test_ranking_loss_batched_gemm_matches_oracle_and_item_kernel():
+    """RankingLoss as exact-fp32 MFMA GEMMs over a whole validation batch, masks from the Corrupter's device tables,
+    accumulated on the device: against the oracle on the reference-generated fixture, and against the
+    wave-per-item kernel on a larger problem that spans several validation chunks and all slots.  A near-tie may flip
+    one comparison per sample (different fp32 summation order), hence 2 / (V - 1) of slack per call."""
+    from golden_util import Golden
+    from codae.tool import RankingLoss
+    from oracle import dae_oracle as O
+    ge = Golden("embedding_square")
+
+    class DS:
+        nb_predictor, nb_used_category, embedding_size = 48, 3, 16
+        data_per_category = {c: torch.tensor(ge["data_per_category"][c]) for c in range(3)}
+
+    class Corr:
+        mask_table_u8 = torch.tensor(ge["binary_masks"]).to(torch.uint8).contiguous().to(dev())
+        mask_to_use_i32 = torch.tensor(ge["mask_to_use"]).to(torch.int32).contiguous().to(dev())
+    val = [int(v) for v in ge["validation_indices"]]
+    rl = RankingLoss(DS(), val, device=dev())
+    rng = np.random.default_rng(4)
+    ref_total = 0.0
+    for call in (6, 7):
+        idx, run = ge.calls()[call]
+        _, fm = O.get_masks(ge["binary_masks"], ge["nb_missing_per_run"], ge["mask_to_use"], 1, idx, run)
+        pred = rng.standard_normal((len(idx), 48)).astype(np.float32)
+        rl.add(torch.tensor(pred, device=dev()), torch.tensor(np.asarray(idx), dtype=torch.int32, device=dev()), Corr, run=run, chunk=32)
+        ref_total += O.ranking_loss(pred, fm, idx, list(ge["data_per_category"]), 16, val)
+    got = rl.total()
+    assert abs(got - ref_total) <= 1e-3 * abs(ref_total) + 4.0 / (len(val) - 1), (got, ref_total)
+    assert rl.total() == 0.0                                     # reset
+
+    # larger: S = 3, E = 64, 3000 observations, 700 validation rows, batch 500, chunks of 256 columns
+    S, E, N, V, B = 3, 64, 3000, 700, 500
+    g = torch.Generator().manual_seed(11)
+
+    class DS2:
+        nb_predictor, nb_used_category, embedding_size = S * E, S, E
+        data_per_category = {c: torch.randn(N, E, generator=g) for c in range(S)}
+    table = torch.ones(S, S * E, dtype=torch.uint8)
+    for c in range(S):
+        table[c, c * E:(c + 1) * E] = 0
+
+    class Corr2:
+        mask_table_u8 = table.to(dev())
+        mask_to_use_i32 = torch.randint(0, S, (N, 2), generator=g, dtype=torch.int32).to(dev())
+    val2 = torch.randperm(N, generator=g)[:V].tolist()
+    rl2 = RankingLoss(DS2(), val2, device=dev())
+    idx = torch.tensor(val2[:B], dtype=torch.int32)
+    pred = torch.randn(B, S * E, generator=g)
+    fmask = table[Corr2.mask_to_use_i32.cpu()[idx.long(), 1].long()].float()
+    ref = rl2.get(pred.to(dev()), fmask.to(dev()), idx.tolist())
+    rl2.add(pred.to(dev()), idx.to(dev()), Corr2, run=1, chunk=256)
+    got = rl2.total()
+    assert abs(got - ref) <= 2.0 * B / (V - 1) * 1e-2 + 1e-6 * abs(ref), (got, ref)     # at most a handful of flipped near-ties
+    assert 0.2 * B < ref < 0.8 * B                                                       # (random predictions rank mid-field)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("rows,cols", [(64, 64), (8, 8), (72, 200), (1536, 1536), (512, 16), (24, 1000)])
 def test_transpose_bf16(rows, cols):
     """The transposed weight shadow the data-gradient GEMM reads: bit-exact W.t() (pure data movement)."""
