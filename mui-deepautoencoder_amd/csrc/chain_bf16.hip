@@ -248,6 +248,12 @@ __global__ __launch_bounds__(CH_NT, 1) void chain_step_kernel(ChainArgs a_by_val
     const int io = a->width[0];
     const bool masked = a->mask_id != nullptr || a->mask_to_use != nullptr;
     const uint32_t relu_flags = a->relu_flags;
+    if (a->scalars != nullptr && blockIdx.x == 0 && threadIdx.x < CODAE_S_N_SLOTS) {
+        // the norm accumulators of this step (the previous step's Adam, the last to read them, ran before this launch):
+        // the grouped weight-gradient launch and the bias finish add to them
+        a->scalars[CODAE_S_GRAD_SQ_SLOTS + threadIdx.x] = 0.0;
+        if (threadIdx.x == 0) a->scalars[CODAE_S_GRAD_SQ] = 0.0;
+    }
 
     // ---- prologue loads, oldest first (vector memory operations retire in order: whatever is requested after the ring's
     //      first units would wait for all of them): the 16 rows' source rows and mask ids, then every layer's bias

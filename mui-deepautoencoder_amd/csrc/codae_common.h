@@ -172,6 +172,7 @@ struct ChainArgs {
     int L, rows, B;                                  // rows: batch padded to a multiple of 64
     int width[CODAE_CHAIN_MAX_LAYERS + 1];           // width[l] = input of layer l, width[L] = output of the last
     uint32_t relu_flags;                             // bit l: layer l ends in a ReLU
+    double* scalars;                                 // not null: workgroup 0 zeroes CODAE_S_GRAD_SQ and the norm slots
     const bf16_t* W[CODAE_CHAIN_MAX_LAYERS];         // bf16 weight shadow   [out][in]
     const bf16_t* Wt[CODAE_CHAIN_MAX_LAYERS];        // transposed shadow    [in][out]
     const float* bias[CODAE_CHAIN_MAX_LAYERS];
@@ -241,6 +242,9 @@ struct BiasFinishJobs {
     int rows[64], cols[64];
     int col_begin[65];       // prefix sum of cols: block -> job lookup
 };
-int launch_bias_finish(const BiasFinishJobs& jobs, double* sumsq, hipStream_t s);
+// optional last block of the same launch: what finish_loss_kernel does with per-workgroup metric sums, WITHOUT resetting the
+// norm accumulators (the chain kernel zeroed them before the weight gradients started adding to them)
+struct LossFinish { double* scalars; double inv_n; const double* parts; int n_parts; };
+int launch_bias_finish(const BiasFinishJobs& jobs, double* sumsq, hipStream_t s, const LossFinish* loss = nullptr);
 
 }  // namespace codae

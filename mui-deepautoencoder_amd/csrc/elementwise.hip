@@ -458,8 +458,26 @@ __global__ __launch_bounds__(NT) void colsum_f32_kernel(const float* __restrict_
 
 // Second stage of every bias gradient (and the deterministic replacement of round 1's float atomics): job j's
 // out[c] = parts[0][c] + parts[1][c] + ... in row order; optionally sum out^2 for clip_grad_norm_.
-__global__ __launch_bounds__(NT) void bias_finish_kernel(BiasFinishJobs jobs, double* __restrict__ sumsq) {
+__global__ __launch_bounds__(NT) void bias_finish_kernel(BiasFinishJobs jobs, double* __restrict__ sumsq, LossFinish lf) {
     __shared__ float red[4];
+    if (lf.scalars != nullptr && blockIdx.x == gridDim.x - 1) {          // the extra block: metric sums of the step
+        __shared__ double lred[2][NT];
+        double a = 0.0, b = 0.0;
+        for (int i = threadIdx.x; i < lf.n_parts; i += NT) { a += lf.parts[2 * i]; b += lf.parts[2 * i + 1]; }
+        lred[0][threadIdx.x] = a; lred[1][threadIdx.x] = b;
+        __syncthreads();
+        for (int o = NT / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) { lred[0][threadIdx.x] += lred[0][threadIdx.x + o]; lred[1][threadIdx.x] += lred[1][threadIdx.x + o]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            lf.scalars[CODAE_S_SQ_FULL] += lred[0][0];
+            lf.scalars[CODAE_S_SQ_PARTIAL] += lred[1][0];
+            lf.scalars[CODAE_S_LAST_LOSS] = lred[0][0] * lf.inv_n;
+            lf.scalars[CODAE_S_STEP_SQ] = 0.0;
+        }
+        return;
+    }
     const int gc = blockIdx.x * NT + threadIdx.x;            // column in the concatenation of all jobs
     float sq = 0.f;
     if (gc < jobs.col_begin[jobs.n]) {
@@ -823,11 +841,13 @@ int launch_colsum_parts_f32(const float* src, int M, int N, float* parts, hipStr
     return CODAE_OK;
 }
 
-int launch_bias_finish(const BiasFinishJobs& jobs, double* sumsq, hipStream_t s) {
+int launch_bias_finish(const BiasFinishJobs& jobs, double* sumsq, hipStream_t s, const LossFinish* loss) {
     CODAE_REQUIRE(jobs.n > 0 && jobs.n <= 64, "bias_finish: %d jobs", jobs.n);
     const int total = jobs.col_begin[jobs.n];
     CODAE_REQUIRE(total > 0, "bias_finish: no columns");
-    hipLaunchKernelGGL(bias_finish_kernel, dim3((total + NT - 1) / NT), dim3(NT), 0, s, jobs, sumsq);
+    LossFinish lf{};
+    if (loss != nullptr) { lf = *loss; CODAE_REQUIRE(lf.scalars && lf.parts && lf.n_parts > 0, "bias_finish: bad loss block"); }
+    hipLaunchKernelGGL(bias_finish_kernel, dim3((total + NT - 1) / NT + (loss != nullptr ? 1 : 0)), dim3(NT), 0, s, jobs, sumsq, lf);
     CODAE_LAUNCH_CHECK();
     return CODAE_OK;
 }

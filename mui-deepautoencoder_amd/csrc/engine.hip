@@ -198,7 +198,7 @@ int check_common(codae_handle h, const codae_buffers* b, int B) {
 
 // db_l = sum of layer l's pending partial column-sum rows, in row order (every layer with pending rows, one launch);
 // with_norm: += sum db^2 into the clip_grad_norm_ slots
-int finish_bias(const codae_engine* e, const codae_buffers* b, hipStream_t s, bool with_norm) {
+int finish_bias(const codae_engine* e, const codae_buffers* b, hipStream_t s, bool with_norm, const LossFinish* loss = nullptr) {
     BiasFinishJobs jobs;
     jobs.n = 0;
     int cols = 0;
@@ -222,7 +222,7 @@ int finish_bias(const codae_engine* e, const codae_buffers* b, hipStream_t s, bo
     if (jobs.n == 0) return CODAE_OK;
     jobs.col_begin[jobs.n] = cols;
     ProfScope prof(e, CODAE_K_BIAS_FINISH, s);
-    return launch_bias_finish(jobs, with_norm ? b->scalars + CODAE_S_GRAD_SQ : nullptr, s);
+    return launch_bias_finish(jobs, with_norm ? b->scalars + CODAE_S_GRAD_SQ : nullptr, s, loss);
 }
 
 // Every 16 rows stream all the weights from L2.  Up to 128 workgroups (16 per XCD) that costs nothing extra per row: 3 x 128
@@ -235,8 +235,10 @@ bool chain_eligible(const codae_engine* e, const codae_buffers* b, int B) {
 }
 
 // gather + forward chain + loss (+ data-gradient chain) of a narrow stack: one launch; then the loss finish
+// (backward: the loss finish is left to the caller's bias-finish launch - *loss_out describes it - and the kernel zeroes
+//  the norm accumulators)
 int run_chain(const codae_engine* e, const codae_buffers* b, const codae_batch* batch, const codae_hyper* hyper, bool backward,
-              hipStream_t s) {
+              hipStream_t s, LossFinish* loss_out = nullptr) {
     const int B = batch->B, L = e->L, rows = e->rows_for(B);
     ChainArgs a{};
     a.L = L; a.rows = rows; a.B = B;
@@ -257,6 +259,7 @@ int run_chain(const codae_engine* e, const codae_buffers* b, const codae_batch* 
     a.inv_n = (float)(1.0 / n_glob);
     a.loss_parts = loss_parts_ptr(e, b);
     a.do_backward = backward ? 1 : 0;
+    a.scalars = loss_out != nullptr ? b->scalars : nullptr;
     const int n_wg = rows / chain_rows_per_workgroup();
     CODAE_REQUIRE(n_wg <= e->loss_part_cap, "chain: %d workgroups exceed the partial-sum rows (%d)", n_wg, e->loss_part_cap);
     int rc;
@@ -268,6 +271,11 @@ int run_chain(const codae_engine* e, const codae_buffers* b, const codae_batch* 
     if (backward)
         for (int l = 0; l < L; ++l) e->parts_pending[l] = n_wg;
     e->norm_scalars_zero = true;
+    if (loss_out != nullptr) {
+        loss_out->scalars = b->scalars; loss_out->inv_n = 1.0 / ((double)B * batch->io);
+        loss_out->parts = loss_parts_ptr(e, b); loss_out->n_parts = n_wg;
+        return CODAE_OK;
+    }
     return launch_finish_loss(b->scalars, 1.0 / ((double)B * batch->io), s, loss_parts_ptr(e, b), n_wg);
 }
 
@@ -970,12 +978,13 @@ int codae_train_step(codae_handle h, const codae_buffers* b, const codae_batch* 
         hipStream_t s = (hipStream_t)stream;
         rcc = join_side(h, s);
         if (rcc) return rcc;
-        rcc = run_chain(h, b, batch, hyper, true, s);
+        LossFinish lf{};
+        rcc = run_chain(h, b, batch, hyper, true, s, &lf);
         if (rcc) return rcc;
         const bool with_norm = hyper->max_grad_norm > 0.f && !h->cfg.no_fused_norm;     // (finish_loss zeroed the norm slots)
         rcc = run_wgrad_grouped(h, b, h->rows_for(batch->B), with_norm, s);
         if (rcc) return rcc;
-        rcc = finish_bias(h, b, s, with_norm);
+        rcc = finish_bias(h, b, s, with_norm, &lf);
         if (rcc) return rcc;
         return update_impl(h, b, hyper, s, with_norm);
     }

@@ -728,6 +728,46 @@ def test_graph_replay_matches_eager_step(S, E, B):
     assert float(d.mean()) <= 1e-5 and float(d.max()) <= 2 * 1e-3 * 6, (float(d.mean()), float(d.max()))
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_fused_step_with_two_blanked_slots_vs_oracle(precision, step_path):
+    """k_max = 2 on the FUSED embedding step (`--nb_missing 2`; data_tool.py:186-226): the mask table then holds every
+    1-subset and every 2-subset of the slots, and a sample's mask id for a run may blank one slot or two.  4 slots x 64:
+    10 mask rows; each step uses another run.  Loss, grad-norm and BOTH metric sums (the partial one weighs exactly the
+    blanked columns) against the oracle on the same batches."""
+    from codae.train import HipEmbeddingTrainer
+    from oracle import dae_oracle as O
+    import random
+    S, E, B, N = 4, 64, 300, 900
+    io = S * E
+    rng = np.random.default_rng(77)
+    sched = O.layer_schedule(io, io, 2, 2, False, "embedding")
+    data = rng.random((N, io), dtype=np.float32)
+    params = O.init_params(sched, rng)
+    bm, nmr, per_k = O.corrupter_tables([{"size": E, "position": s * E} for s in range(S)], 2)
+    assert bm.shape[0] == 10 and per_k == [4, 6] and int((bm == 0).sum(1).max()) == 2 * E
+    mtu = O.corrupter_mask_to_use(N, bm.shape[0], random.Random(5))
+    lr, wd = 1e-3, 1e-4
+    tr = HipEmbeddingTrainer(sched, torch.tensor(data), torch.tensor(bm).to(torch.uint8), torch.tensor(mtu).to(torch.int32),
+                             lr, wd, 1.0, max_batch=B, precision=precision, device=DEV)
+    tr.load_params(params)
+    orc = O.EmbeddingTrainer(params, [r for _, _, r in sched], lr, wd)
+    tol = 1e-3 if precision == "f32" else 2e-2
+    two = 0
+    sq_ref = sqp_ref = 0.0
+    for run in (0, 3, 9):
+        idx = rng.permutation(N)[:B]
+        _, fmask = O.get_masks(bm, nmr, mtu, 2, idx, run)
+        two += int(((fmask == 0).sum(1) == 2 * E).sum())
+        ro = orc.step(data[idx], fmask)
+        tr.train_batch(torch.tensor(idx, dtype=torch.int32, device=DEV), run=run)
+        sq, sqp, gsq, loss = tr.engine.read_scalars()
+        assert abs(loss - float(ro["loss"])) <= tol * abs(float(ro["loss"])), (run, loss, ro["loss"])
+        assert abs(math.sqrt(gsq) - float(ro["grad_norm"])) <= 5 * tol * float(ro["grad_norm"]), (run, math.sqrt(gsq), ro["grad_norm"])
+        sq_ref += float(ro["sq_full"]); sqp_ref += float(ro["sq_partial"])
+        assert abs(sq - sq_ref) <= tol * sq_ref and abs(sqp - sqp_ref) <= tol * sqp_ref, (run, sq, sq_ref, sqp, sqp_ref)
+    assert two > B                          # (6 of the 10 mask rows blank two slots)
+
+
 def _fuzz_cases():
     rng = np.random.default_rng(2024)
     cases = []
