@@ -888,12 +888,10 @@ static int update_impl(codae_handle h, const codae_buffers* b, const codae_hyper
     const bool scalars_zero = h->norm_scalars_zero;
     h->norm_scalars_zero = false;
     (void)scalars_zero;
-    if (hyper->max_grad_norm > 0.f) {
-        ProfScope prof(h, CODAE_K_SUMSQ, s);
+    if (hyper->max_grad_norm > 0.f && !weights_norm_done) {    // (else: sum g^2 was accumulated by the slab reduces / the
+        ProfScope prof(h, CODAE_K_SUMSQ, s);                    //  grouped weight-gradient epilogues and the bias finish)
         int rc;
-        if (weights_norm_done) {
-            rc = CODAE_OK;     // sum g^2 of every weight and bias gradient was accumulated by the slab reduces
-        } else {
+        {
             if (!scalars_zero) {                 // (a stand-alone update: no step_forward_loss of this step cleared them)
                 CODAE_HIP_CHECK(hipMemsetAsync(b->scalars + CODAE_S_GRAD_SQ, 0, sizeof(double), s));
                 CODAE_HIP_CHECK(hipMemsetAsync(b->scalars + CODAE_S_GRAD_SQ_SLOTS, 0, CODAE_S_N_SLOTS * sizeof(double), s));
