@@ -97,6 +97,7 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
     auto b_img = [&](int tile, int h) { return smem + (tile & 1) * BUF + 2 * AH + h * BH; };
     // timing-only ablations (compile-time; DBG = 0 in the shipped instantiations)
     constexpr bool dbg_noload = DBG & 1, dbg_nomma = DBG & 2, dbg_nostore = DBG & 4, dbg_time = DBG & 8;
+    constexpr bool dbg_no_a = DBG & 16, dbg_no_b = DBG & 32;        // only one operand's LDS-DMA
     auto stamp = [&](int slot) {
         if constexpr (dbg_time) {
             if (threadIdx.x == 0 && blockIdx.x < TIMELINE_WGS) g_timeline[blockIdx.x * TIMELINE_SLOTS + slot] = wall_clock64();
@@ -160,7 +161,7 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
     // the schedule assigns: every phase stays one straight-line block the scheduler can interleave,
     // and the vmcnt arithmetic is exact to the end (cost: ~2 extra K-tiles of L2-hit DMA per workgroup).
     auto issue_a = [&](int tile, int h) {
-        if constexpr (!dbg_noload && a_loader) {
+        if constexpr (!dbg_noload && !dbg_no_a && a_loader) {
             const char* base = a_base + (int64_t)(tile < nkt ? tile : nkt - 1) * a_step;      // wave-uniform
             lds_char* img = a_img(tile, h);
 #pragma unroll
@@ -168,7 +169,7 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
         }
     };
     auto issue_b = [&](int tile, int h) {
-        if constexpr (!dbg_noload && b_loader) {
+        if constexpr (!dbg_noload && !dbg_no_b && b_loader) {
             const char* base = b_base + (int64_t)(tile < nkt ? tile : nkt - 1) * b_step;
             lds_char* img = b_img(tile, h);
 #pragma unroll
@@ -671,6 +672,8 @@ int gemm_bf16_pipe(const GemmBf16& g, int cfg, hipStream_t s) {
             case 8: return launch_dbg<8>(g, s);
             case 9: return launch_dbg<9>(g, s);      // stamps + no LDS-DMA
             case 10: return launch_dbg<10>(g, s);    // stamps + no MFMA
+            case 16: return launch_dbg<16>(g, s);    // no LDS-DMA of the A operand
+            case 32: return launch_dbg<32>(g, s);    // no LDS-DMA of the B operand
             default: break;
         }
     }
