@@ -350,6 +350,7 @@ int run_wgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, hi
                                        e->norm_in_backward ? b->scalars + CODAE_S_GRAD_SQ : nullptr, s);
         }
         g.C = dW;
+        if (e->norm_in_backward) g.sumsq_slots = b->scalars + CODAE_S_GRAD_SQ_SLOTS;    // (unsplit: the epilogue sees the final values)
         ProfScope prof(e, CODAE_K_GEMM_WGRAD, s);
         return gemm_bf16(g, s);
     }
@@ -990,10 +991,8 @@ int codae_train_step(codae_handle h, const codae_buffers* b, const codae_batch* 
     if (rc) return rc;
     // single GPU: nothing happens to the gradients between backward and update, so the norm can be
     // gathered while the split-K slabs are reduced (finish_loss zeroed GRAD_SQ before the backward)
-    const int rows = h->rows_for(batch->B);
-    bool all_slabbed = h->prec == CODAE_PREC_BF16 && hyper->max_grad_norm > 0.f && !h->cfg.no_fused_norm;
-    for (int l = 0; l < h->L && all_slabbed; ++l)
-        if ((h->split_k[l] <= rows / 64 ? h->split_k[l] : rows / 64) <= 1) all_slabbed = false;
+    // bf16: every weight gradient leaves its sum g^2 behind - split ones in the slab reduce, unsplit ones in the GEMM epilogue
+    const bool all_slabbed = h->prec == CODAE_PREC_BF16 && hyper->max_grad_norm > 0.f && !h->cfg.no_fused_norm;
     h->norm_in_backward = all_slabbed;
     rc = codae_step_backward(h, b, batch->B, 0, h->L, stream);
     h->norm_in_backward = false;

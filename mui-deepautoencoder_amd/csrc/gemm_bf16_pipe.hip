@@ -578,6 +578,7 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
         const float floor_v = g.relu ? 0.f : -__builtin_inff();
         const int c = threadIdx.x % CH, rl = threadIdx.x / CH;
         const int j = j0 + c * 4;
+        float sq = 0.f;                                  // sum of the stored values' squares (g.sumsq_slots)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
@@ -603,9 +604,24 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
                 const int r = rl + it * RL;
                 const bool ok = rl < RL && j < g.N && r < HR && i0 + hh * HR + r < g.M;
                 const f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(smem + (ok ? r : 0) * PITCH + c * 16);
-                if (ok) *reinterpret_cast<float4*>(Cf + (int64_t)(i0 + hh * HR + r) * g.ldc + j) = make_float4(v[0], v[1], v[2], v[3]);
+                if (ok) {
+                    *reinterpret_cast<float4*>(Cf + (int64_t)(i0 + hh * HR + r) * g.ldc + j) = make_float4(v[0], v[1], v[2], v[3]);
+                    sq += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+                }
             }
             __syncthreads();
+        }
+        if (g.sumsq_slots != nullptr) {      // an unsplit weight gradient: clip_grad_norm_'s sum g^2 without a pass of its own
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+            float* red = reinterpret_cast<float*>(smem_raw);
+            if (lane == 0) red[w] = sq;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float t = 0.f;
+                for (int ww = 0; ww < NW; ++ww) t += red[ww];
+                atomicAdd(g.sumsq_slots + (blockIdx.x & (CODAE_S_N_SLOTS - 1)), (double)t);
+            }
         }
     }
 }
