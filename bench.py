@@ -316,6 +316,7 @@ def main():
                        "mfma_roofline_frac_whole_step": (fps * value / world) / (peak * 1e12)},
             "final_loss": loss, "final_grad_norm": gnorm,
             "host_enqueue_ms_per_step": 1e3 * enqueue_s / args.steps,
+            "step_path": ("layers (bucketed backward + collectives)" if distributed else tr.engine.step_path(B)),
             "f32_parity": f32_parity,
         }
         if dp_info is not None:

@@ -36,8 +36,9 @@ extern "C" {
  *   1: round 1 as first published (9-field codae_buffers)
  *   2: codae_buffers.shadow_wt, CODAE_S_ADAM_STEP / CODAE_S_COUNT 80, codae_struct_sizes, codae_reload_env,
  *      codae_train_step_graph, codae_step_backward_async, codae_side_stream, codae_join, codae_profile_stride
- *   3: codae_chain_*, CODAE_K_* additions, codae_reduce_* (this round; see the entries' comments)
- *   4: + codae_ranking_loss_batched, codae_gather_inventory_rows (new entries only; no layout change)
+ *   3: codae_buffers.bias_parts, codae_sizes.bias_part_bytes, CODAE_K_CHAIN / CODAE_K_BIAS_FINISH, codae_span_sumsq,
+ *      codae_step_update_span, codae_sync_transposed, codae_dgrad_bf16's partial-sum workspace
+ *   4: + codae_ranking_loss_batched, codae_gather_inventory_rows, codae_step_path (new entries only; no layout change)
  * The binding must refuse a library whose codae_abi_version() differs and must check its own struct sizes against
  * codae_struct_sizes() at load (mui-deepautoencoder_amd/codae/hip/__init__.py does both). */
 #define CODAE_ABI_VERSION 4
@@ -226,14 +227,18 @@ int codae_step_update_span(codae_handle h, const codae_buffers* bufs, const coda
                            const double* total_sq, void* stream);
 /* shadow_wt <- transpose(shadow_w) for every layer that has a data gradient (BF16 mode; no-op otherwise) */
 int codae_sync_transposed(codae_handle h, const codae_buffers* bufs, void* stream);
-/* all three, single GPU.  Narrow stacks (bf16, every width <= 512, at most 15 layers, batch <= 8192 rows) take the
- * persistent fused chain instead of per-layer launches: ONE kernel for gather + corruption + all forward layers +
- * loss + the whole data-gradient chain (a workgroup walks 16 batch rows through every layer; weights stream from
- * L2), ONE grouped launch for every layer's weight gradient, then bias finish, loss finish, norm, Adam: 6 launches
- * instead of ~55 (the reference's stock BATCH_SIZE 128 and BASELINE config 2 are launch-bound).  Same arithmetic, same
- * buffers; CODAE_NO_CHAIN=1 keeps the per-layer path. */
+/* all three, single GPU.  Narrow stacks (bf16, every width a multiple of 64 and <= 512, at most 15 layers, widths summing
+ * to <= 6144, batch <= 2048 rows) take the persistent fused chain instead of per-layer launches: ONE kernel for gather +
+ * corruption + all forward layers + loss + the whole data-gradient chain (a workgroup walks 16 batch rows through every
+ * layer; weights stream from L2 through per-wave LDS rings), ONE grouped launch for every layer's weight gradient (with
+ * the norm's sum g^2), bias finish + loss finish, Adam: 4 launches instead of ~55 (the reference's stock BATCH_SIZE 128
+ * on a narrow stack and BASELINE config 2 are launch-bound).  Same arithmetic, same buffers; CODAE_NO_CHAIN=1 keeps
+ * the per-layer path; codae_step_path tells which one a batch size takes. */
 int codae_train_step(codae_handle h, const codae_buffers* bufs, const codae_batch* batch,
                      const codae_hyper* hyper, void* stream);
+/* 1 if codae_train_step / codae_eval_step with B rows run the persistent chain on this engine and these buffers, 0 if the
+ * per-layer launches (tests and bench lines name the path they measured) */
+int codae_step_path(codae_handle h, const codae_buffers* bufs, int32_t B);
 /* validation body (:245-258): forward + metric sums only */
 int codae_eval_step(codae_handle h, const codae_buffers* bufs, const codae_batch* batch, float* out_y,
                     void* stream);

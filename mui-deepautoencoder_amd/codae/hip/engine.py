@@ -240,6 +240,10 @@ class DaeEngine:
     def new_accumulator(self):
         return torch.zeros(1, dtype=torch.float64, device=self.device)
 
+    def step_path(self, B):
+        """'chain' if a fused step of B rows runs the persistent chain kernel, 'layers' for per-layer launches."""
+        return "chain" if self._lib.codae_step_path(self._h, C.byref(self.bufs), int(B)) == 1 else "layers"
+
     def eval_step(self, batch, out_y=None):
         with torch.cuda.device(self.device):
             check(self._lib.codae_eval_step(self._h, C.byref(self.bufs), C.byref(batch), ptr(out_y), current_stream()))

@@ -41,10 +41,15 @@ class _ChainFunction(torch.autograd.Function):
             raise HipError("backward through a forward whose activations were overwritten by a later forward; "
                            "call backward before running the model again")
         dx = eng.backward(dy, lo, hi, need_dx=ctx.needs_input_grad[0])
+        # One copy of the engine's flat gradient vector, handed out as views: autograd keeps (or accumulates) them as
+        # .grad, and the next backward overwrites the engine's own buffer, so the parameters must not alias it.  (Round 1
+        # cloned the 2 L tensors one by one: 20 launches per backward.)
+        eng.join()                           # (weight gradients run on the engine's side stream)
+        flat = eng.grads.clone()
         grads = [None] * ctx.n_params
         for l in range(lo, hi):
-            grads[2 * l] = eng.weight_grad(l).clone()
-            grads[2 * l + 1] = eng.bias_grad(l).clone()
+            grads[2 * l] = eng._view(flat, l, False)
+            grads[2 * l + 1] = eng._view(flat, l, True)
         return (dx, None, None, None, *grads)
 
 

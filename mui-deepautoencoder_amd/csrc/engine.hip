@@ -961,6 +961,10 @@ int codae_join(codae_handle h, void* stream) {
     return join_side(h, (hipStream_t)stream);
 }
 
+int codae_step_path(codae_handle h, const codae_buffers* b, int32_t B) {
+    return (h != nullptr && b != nullptr && B > 0 && B <= h->max_batch && chain_eligible(h, b, B)) ? 1 : 0;
+}
+
 int codae_train_step(codae_handle h, const codae_buffers* b, const codae_batch* batch, const codae_hyper* hyper, void* stream) {
     CODAE_REQUIRE(hyper != nullptr, "codae_train_step: null hyper");
     CODAE_REQUIRE(batch != nullptr, "codae_train_step: null batch");

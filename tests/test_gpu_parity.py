@@ -381,10 +381,15 @@ def test_chain_step_equals_per_layer_step(monkeypatch, group_tile):
         monkeypatch.delenv("CODAE_GROUP_TILE", raising=False)
     else:
         monkeypatch.setenv("CODAE_GROUP_TILE", group_tile)
-    for (S, E, z, nl, B) in ((3, 128, 384, 4, 1024), (3, 64, 64, 2, 333)):
+    cases = [(3, 128, 384, 4, 1024), (3, 64, 64, 2, 333)]
+    if group_tile == "auto":
+        # the chain's limits: widest panel (512), one sample (15 pad rows), 15 layers, the row limit itself (128 workgroups)
+        cases += [(4, 128, 512, 2, 200), (3, 64, 192, 2, 1), (2, 64, 128, (7, 6), 100), (3, 64, 192, 2, 2048)]
+    for (S, E, z, nl, B) in cases:
         io = S * E
         rng = np.random.default_rng(B)
-        sched = O.layer_schedule(io, z, nl, nl, False, "embedding")
+        n_in, n_out = nl if isinstance(nl, tuple) else (nl, nl)
+        sched = O.layer_schedule(io, z, n_in, n_out, False, "embedding")
         params = O.init_params(sched, rng)
         data = torch.tensor(rng.random((B + 50, io), dtype=np.float32), device=DEV)
         bm, _, _ = O.corrupter_tables([{"size": E, "position": s * E} for s in range(S)], 1)
@@ -398,6 +403,7 @@ def test_chain_step_equals_per_layer_step(monkeypatch, group_tile):
             else:
                 monkeypatch.setenv("CODAE_NO_CHAIN", "1")
             eng = DaeEngine(sched, B, "bf16", DEV)
+            assert eng.step_path(B) == ("chain" if chain else "layers"), (S, E, z, nl, B)
             eng.load_params(params)
             batch = eng.make_batch(data, rows, mid, table)
             eng.train_step(batch, eng.hyper(1e-3, 1e-4, clip=1.0, global_rows=B))
