@@ -1,6 +1,7 @@
 """Chain of 10 forward GEMMs (8192 x 1536 x 1536, bias + ReLU): one full-batch chain on one stream vs
 two half-batch chains on two streams (each CU then holds a workgroup of each chain when the 128x192 tile
-is used).  Prints wall time per chain of 10 layers."""
+is used).  Prints wall time per chain of 10 layers.  A third argument starts the second half-chain half a layer late, so
+that one chain's output drain meets the other's K loop (r02: no gain either way: 407 vs 371-400 us per 10 layers)."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mui-deepautoencoder_amd"))
 import torch
@@ -21,10 +22,14 @@ def gemm(l, r0, rows, stream):
 s0 = torch.cuda.current_stream(); s1 = torch.cuda.Stream(); s2 = torch.cuda.Stream()
 def full():
     for l in range(LAYERS): gemm(l, 0, M, s0)
+OFFSET = len(sys.argv) > 3        # third argument: start the second chain half a layer late (a K/2 GEMM in front of it)
+xh = acts[0][:4096, :K // 2].contiguous(); Wh = Ws[0][:, :K // 2].contiguous(); yh = torch.empty(4096, N, device=dev, dtype=torch.bfloat16)
 def halves(parts):
     streams = [s0, s1, s2][:len(parts)]
     ev = torch.cuda.Event(); ev.record(s0)
     for st in streams[1:]: st.wait_event(ev)
+    if OFFSET:
+        hip.check(L.codae_linear_bf16(hip.ptr(xh), hip.ptr(Wh), hip.ptr(b), hip.ptr(yh), 0, 4096, N, K // 2, 1, hip.C.c_void_p(s1.cuda_stream)))
     for l in range(LAYERS):
         for (r0, rows), st in zip(parts, streams): gemm(l, r0, rows, st)
     for st in streams[1:]:
