@@ -286,5 +286,10 @@ class DaeEngine:
         gsq = float(s[S_GRAD_SQ]) + float(s[S_GRAD_SQ_SLOTS:S_GRAD_SQ_SLOTS + S_N_SLOTS].sum())
         return float(s[S_SQ_FULL]), float(s[S_SQ_PARTIAL]), gsq, float(s[S_LAST_LOSS])
 
+    def record_grad_sq(self, acc):
+        """The sharded data-parallel update gathers the global sum g^2 in its own accumulator: keep it where a fused
+        step leaves it (scalars[GRAD_SQ]; the slots stay zero on that path)."""
+        self.scalars[S_GRAD_SQ:S_GRAD_SQ + 1].copy_(acc.reshape(1))
+
     def zero_metric_sums(self):
         self.scalars[:2].zero_()

@@ -259,6 +259,8 @@ class DataParallel:
             eng.span_sumsq(eng.b_off[0], eng.n_param, acc)
         self.dist.all_reduce(acc, op=self.dist.ReduceOp.SUM, group=self.group)
         self.last_grad_sq = acc
+        if hasattr(eng, "record_grad_sq"):
+            eng.record_grad_sq(acc)          # where read_scalars() / last_loss_and_grad_norm() look for the step's sum g^2
         for lo, hi in self.buckets:
             a, b = self._shard_bounds(lo, hi)
             eng.step_update_span(hyper, a, b, acc)
