@@ -1,4 +1,4 @@
-"""Data-parallel step of the REAL engine with world_size 2: two processes share the one GPU of the test box and talk over
+"""Data-parallel step of the REAL engine with world_size 2 and 4: the processes share the one GPU of the test box and talk over
 gloo (RCCL refuses two ranks on one device; the collectives are what `torch.distributed` gives either way).  This is the
 only place where the engine's span entry points (codae_span_sumsq, codae_step_update_span on a span that does not start
 at 0, the shadow all-gather, codae_sync_transposed) and the bucketed all-reduce run with more than one rank on hardware:
@@ -73,17 +73,16 @@ def _worker(rank, world, port, out_dir, sharded):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("sharded", [False, True], ids=["allreduce", "sharded"])
-def test_two_ranks_on_one_gpu_match_the_global_batch_step(tmp_path, monkeypatch, sharded):
+@pytest.mark.parametrize("world,sharded", [(2, False), (2, True), (4, True)], ids=["allreduce-2", "sharded-2", "sharded-4"])
+def test_ranks_on_one_gpu_match_the_global_batch_step(tmp_path, monkeypatch, world, sharded):
     import torch.multiprocessing as mp
-    world = 2
-    mp.get_context("spawn")
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), sharded), nprocs=world, join=True)
     p = [np.load(tmp_path / ("params_%d.npy" % r)) for r in range(world)]
     sh = [np.load(tmp_path / ("shadow_%d.npy" % r)) for r in range(world)]
     st = [np.load(tmp_path / ("shadow_t_%d.npy" % r)) for r in range(world)]
-    assert np.array_equal(p[0], p[1]), "fp32 replicas diverged"
-    assert np.array_equal(sh[0], sh[1]) and np.array_equal(st[0], st[1]), "bf16 shadows (what the next forward / dgrad read) diverged"
+    for r in range(1, world):
+        assert np.array_equal(p[0], p[r]), "fp32 replicas diverged"
+        assert np.array_equal(sh[0], sh[r]) and np.array_equal(st[0], st[r]), "bf16 shadows (what the next forward / dgrad read) diverged"
     # single process, whole batch, per-layer path
     monkeypatch.setenv("CODAE_NO_CHAIN", "1")
     tr, order = _trainer(False, False)
