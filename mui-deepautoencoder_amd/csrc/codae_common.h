@@ -89,7 +89,7 @@ struct EnvToggles {
     int group_tile = -1;         // CODAE_GROUP_TILE: grouped weight gradients on 128 x 128 (0), 64 x 128 (1), 64 x 64 (2); -1 = automatic
     bool side_priority_set = false; int side_priority = 0;   // CODAE_SIDE_PRIORITY
     bool no_wt = false, single_stream = false, tail_on_side = false, no_fused_loss = false, flat_adam = false,
-         no_fused_norm = false, no_chain = false;
+         no_fused_norm = false, no_chain = false, no_deep_small = false;      // CODAE_NO_DEEP_SMALL: 2-stage small GEMMs
 };
 const EnvToggles& env();
 void env_reload();

@@ -39,6 +39,7 @@ void env_reload() {
     e.flat_adam = getenv("CODAE_FLAT_ADAM") != nullptr;
     e.no_fused_norm = getenv("CODAE_NO_FUSED_NORM") != nullptr;
     e.no_chain = getenv("CODAE_NO_CHAIN") != nullptr;
+    e.no_deep_small = getenv("CODAE_NO_DEEP_SMALL") != nullptr;
     g_env = e;
     g_env_loaded = true;
 }
@@ -159,6 +160,9 @@ struct GroupScope {
 int choose_split_k(int N, int K, int rows) {
     const int kt = rows / 64;
     int s;
+    // a batch of <= 256 rows is 1-4 K-tiles: the launch is all epilogue (the fp32 output), which a split multiplies and
+    // follows with a reduce (stock BATCH_SIZE 128 at io 1536: 18.8 + 13 us per layer split in two)
+    if (kt <= 4 && env().wgrad_splitk <= 0) return 1;
     if (env().wgrad_splitk > 0) {
         s = env().wgrad_splitk;
     } else {

@@ -153,9 +153,13 @@ __device__ __forceinline__ bf16x8 read_frag(const lds_char* tile, int t, int s, 
 // Tile BM x BN x 64, WM x WN waves, each wave (BM/WM) x (BN/WN) = TM x TN MFMA tiles of 16 x 16.
 // One output tile of one GEMM: the whole kernel body, so that the plain kernel (one GEMM per launch) and the grouped
 // kernel (several GEMMs per launch) share it.  wg / nwg: this workgroup's index among the nwg workgroups of ITS GEMM.
-template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, bool C_F32, bool LOSS>
+// NS = operand stages in LDS.  2: the one-barrier double buffer (tile t + 1 requested while t is multiplied).  4: tiles up to
+// t + 3 in flight, for launches too small to fill the chip - a 128-row batch of a wide layer is 12 workgroups, each
+// walking its 24 K-tiles of COLD weights one memory latency at a time (27 us for 0.6 GFLOP with NS = 2).
+template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, bool C_F32, bool LOSS, int NS = 2>
 __device__ __forceinline__ void gemm_bf16_tile(const GemmBf16& g, int tiles_n, int tiles_mn, int kt_total, int wg, int nwg,
                                                char* smem_raw) {
+    static_assert(NS == 2 || (NS == 4 && !LOSS), "2 or 4 stages (the fused-loss epilogue keeps its row table behind 2)");
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
@@ -200,20 +204,35 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmBf16& g, int tiles_n, i
         }
     }
 
+    // LDS-DMA pieces a wave issues per stage; with NS > 2 requests past the last K-tile re-read it into a slot nobody is
+    // reading (slot t mod NS: no live tile shares it), so that the counted waits stay exact to the end
+    constexpr int PIECES = (BM + BN) * 128 / 1024 / NW;
+    auto stage = [&](int t) {
+        const int tc = t < nkt ? t : nkt - 1;
+        lds_char* dst = smem + (t % NS) * BUF_BYTES;
+        const int k0 = (kt_begin + tc) * BK;
+        stage_tile<A_MODE, BM, NW>(dst, g.A, g.lda, i0, g.M, k0, w, lane);
+        stage_tile<B_MODE, BN, NW>(dst + A_BYTES, g.B, g.ldb, j0, g.N, k0, w, lane);
+    };
+    // (NS > 2: a raw barrier - __syncthreads() carries a fence that waits vmcnt(0), i.e. for the whole prefetch queue)
+    auto tile_barrier = [&]() {
+        if constexpr (NS > 2) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            __syncthreads();
+        }
+    };
     if (nkt > 0) {
-        stage_tile<A_MODE, BM, NW>(smem, g.A, g.lda, i0, g.M, kt_begin * BK, w, lane);
-        stage_tile<B_MODE, BN, NW>(smem + A_BYTES, g.B, g.ldb, j0, g.N, kt_begin * BK, w, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NS - 1; ++t) stage(t);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * (NS - 2)) : "memory");
+        tile_barrier();
     }
     for (int kt = 0; kt < nkt; ++kt) {
-        lds_char* cur = smem + (kt & 1) * BUF_BYTES;
-        lds_char* nxt = smem + ((kt + 1) & 1) * BUF_BYTES;
-        if (kt + 1 < nkt) {
-            const int k0 = (kt_begin + kt + 1) * BK;
-            stage_tile<A_MODE, BM, NW>(nxt, g.A, g.lda, i0, g.M, k0, w, lane);
-            stage_tile<B_MODE, BN, NW>(nxt + A_BYTES, g.B, g.ldb, j0, g.N, k0, w, lane);
-        }
+        lds_char* cur = smem + (kt % NS) * BUF_BYTES;
+        if (NS > 2 || kt + 1 < nkt) stage(kt + NS - 1);
         // fragments of BOTH k-steps are requested up front: the MFMAs of k-step 0 start as soon as
         // their operands are back (counted lgkmcnt) while the reads of k-step 1 are still in flight
         bf16x8 af[2][TM], bfr[2][TN];
@@ -241,6 +260,10 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmBf16& g, int tiles_n, i
                     // swapped operands: D rows <-> output column (n), D cols <-> output row (m)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s][nt], af[s][mt], acc[mt][nt], 0, 0, 0);
         }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * (NS - 2)) : "memory");     // tile kt + 1 has landed
+        tile_barrier();
+    }
+    if constexpr (NS > 2) {          // the trailing re-requests land before the epilogue reuses the buffers
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -514,13 +537,13 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmBf16& g, int tiles_n, i
     }
 }
 
-template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, bool C_F32, bool LOSS = false>
-__global__ __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256 * ((2 * (BM + BN) * 128 <= 80 * 1024) ? 2 : 1))
+template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, bool C_F32, bool LOSS = false, int NS = 2>
+__global__ __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256 * ((NS * (BM + BN) * 128 <= 80 * 1024) ? 2 : 1))
 void gemm_bf16_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
     // LOSS: + {dataset row, mask id} of the tile's rows, fetched once at entry (two dependent loads that
     // would otherwise sit in front of every row of the epilogue)
-    __shared__ __attribute__((aligned(16))) char smem_raw[2 * (BM + BN) * 128 + (LOSS ? BM * 8 : 0)];
-    gemm_bf16_tile<BM, BN, WM, WN, A_MODE, B_MODE, C_F32, LOSS>(g, tiles_n, tiles_mn, kt_total, blockIdx.x, gridDim.x, smem_raw);
+    __shared__ __attribute__((aligned(16))) char smem_raw[NS * (BM + BN) * 128 + (LOSS ? BM * 8 : 0)];
+    gemm_bf16_tile<BM, BN, WM, WN, A_MODE, B_MODE, C_F32, LOSS, NS>(g, tiles_n, tiles_mn, kt_total, blockIdx.x, gridDim.x, smem_raw);
 }
 
 // Several weight-gradient GEMMs (k-strided operands, fp32 output) in one launch: workgroup -> (GEMM, tile) by the prefix
@@ -548,7 +571,15 @@ int launch_cfg(const GemmBf16& g, hipStream_t s) {
     if (g.loss.enabled) {
         hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, OP_KC, OP_KC, false, true>), grid, block, 0, s, g, tiles_n,
                            tiles_m * tiles_n, kt_total);
-    } else if (g.a_mode == OP_KC && g.b_mode == OP_KC) { if (g.c_f32) LAUNCH(OP_KC, OP_KC, true); else LAUNCH(OP_KC, OP_KC, false); }
+    } else if (g.a_mode == OP_KC && g.b_mode == OP_KC) {
+        // forward / data-gradient form of a launch that cannot fill the chip: four stages (see gemm_bf16_tile)
+        const bool deep = !g.c_f32 && nwg <= 256 && kt_total >= 6 && !env().no_deep_small;
+        if (g.c_f32) LAUNCH(OP_KC, OP_KC, true);
+        else if (deep)
+            hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, OP_KC, OP_KC, false, false, 4>), grid, block, 0, s, g, tiles_n,
+                               tiles_m * tiles_n, kt_total);
+        else LAUNCH(OP_KC, OP_KC, false);
+    }
     else if (g.a_mode == OP_KC && g.b_mode == OP_KS) { if (g.c_f32) LAUNCH(OP_KC, OP_KS, true); else LAUNCH(OP_KC, OP_KS, false); }
     else if (g.a_mode == OP_KS && g.b_mode == OP_KS) { if (g.c_f32) LAUNCH(OP_KS, OP_KS, true); else LAUNCH(OP_KS, OP_KS, false); }
     else { set_error("gemm_bf16: operand mode combination not built"); return CODAE_E_UNSUPPORTED; }
