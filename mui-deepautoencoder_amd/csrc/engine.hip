@@ -40,6 +40,7 @@ void env_reload() {
     e.no_fused_norm = getenv("CODAE_NO_FUSED_NORM") != nullptr;
     e.no_chain = getenv("CODAE_NO_CHAIN") != nullptr;
     e.no_deep_small = getenv("CODAE_NO_DEEP_SMALL") != nullptr;
+    if (const char* k = getenv("CODAE_SMALL_TILE_MAX")) e.small_tile_max = atoi(k);
     g_env = e;
     g_env_loaded = true;
 }
@@ -83,7 +84,8 @@ struct codae_engine {
     // backward on two streams: the weight-gradient GEMMs (+ slab reduce) run on `side`, concurrently with
     // the data-gradient chain on the caller's stream (they only share the read-only dA_l)
     mutable hipStream_t side = nullptr;
-    mutable hipEvent_t ev_ready = nullptr, ev_join = nullptr, ev_w[CODAE_MAX_DACT] = {};
+    mutable hipEvent_t ev_ready[CODAE_MAX_DACT] = {}, ev_join = nullptr, ev_w[CODAE_MAX_DACT] = {};
+    mutable unsigned ready_turn = 0;        // ev_ready is used round robin: an event is re-recorded 16 hand-offs later at the earliest
     // dA buffer i is still being read by a side-stream wgrad (event ev_w[i]); kept across calls so that a backward
     // issued bucket by bucket without joins (codae_step_backward_async) stays ordered
     mutable bool w_pending[CODAE_MAX_DACT] = {};
@@ -443,7 +445,7 @@ int ensure_side_stream(const codae_engine* h) {
     CODAE_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
     const int prio = h->cfg.side_priority_set ? h->cfg.side_priority : prio_least;
     CODAE_HIP_CHECK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio));
-    CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
+    for (int i = 0; i < CODAE_MAX_DACT; ++i) CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_ready[i], hipEventDisableTiming));
     CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     for (int i = 0; i < CODAE_MAX_DACT; ++i) CODAE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_w[i], hipEventDisableTiming));
     return CODAE_OK;
@@ -491,8 +493,9 @@ int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi
             // nothing left to do: the last weight gradient runs here (third slab buffer), beside wgrad_1
             rc = run_wgrad(h, b, l, rows, s, 2);
         } else {
-            CODAE_HIP_CHECK(hipEventRecord(h->ev_ready, s));                // dA_l (and act[l]) are complete on s
-            CODAE_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_ready, 0));
+            hipEvent_t ready = h->ev_ready[h->ready_turn++ % CODAE_MAX_DACT];
+            CODAE_HIP_CHECK(hipEventRecord(ready, s));                      // dA_l (and act[l]) are complete on s
+            CODAE_HIP_CHECK(hipStreamWaitEvent(h->side, ready, 0));
             rc = run_wgrad(h, b, l, rows, h->side, l & 1);                  // two alternating slab buffers
             if (rc == CODAE_OK && h->n_dact <= h->L) {   // (with a buffer per layer nothing is overwritten within a step)
                 CODAE_HIP_CHECK(hipEventRecord(h->ev_w[l % h->n_dact], h->side));
@@ -620,7 +623,7 @@ int codae_create(const codae_spec* spec, codae_handle* out) {
     {   // + the loss kernels' per-workgroup metric sums: [workgroups][2] doubles
         const int io = e->out[e->L - 1];
         const int by_rows = (e->max_rows + 31) / 32;                                             // stand-alone loss kernel
-        const int by_tiles = ((e->max_rows + 127) / 128) * ((io + 127) / 128);                   // fused into the last GEMM
+        const int by_tiles = ((e->max_rows + 63) / 64) * ((io + 63) / 64);                       // fused into the last GEMM (smallest tile)
         e->loss_part_cap = by_rows > by_tiles ? by_rows : by_tiles;
         if (e->chain_ok && chain_rows / 16 > e->loss_part_cap) e->loss_part_cap = chain_rows / 16;
         e->loss_part_off = e->part_floats;
@@ -652,7 +655,8 @@ int codae_destroy(codae_handle h) {
     if (h && h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
     if (h && h->side) {
         (void)hipStreamSynchronize(h->side);
-        (void)hipEventDestroy(h->ev_ready); (void)hipEventDestroy(h->ev_join);
+        for (int i = 0; i < CODAE_MAX_DACT; ++i) if (h->ev_ready[i]) (void)hipEventDestroy(h->ev_ready[i]);
+        (void)hipEventDestroy(h->ev_join);
         for (int i = 0; i < CODAE_MAX_DACT; ++i) (void)hipEventDestroy(h->ev_w[i]);
         (void)hipStreamDestroy(h->side);
     }

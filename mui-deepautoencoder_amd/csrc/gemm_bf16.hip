@@ -644,16 +644,32 @@ int gemm_bf16_tile_big(int M, int N, int split_k, bool k_strided = false) {
     return 6;
 }
 
+// Forward / data-gradient form (k-contiguous operands, bf16 out) of a launch with at most 200 tiles of 128 x 128 - a small
+// batch of a wide layer, or a narrow layer: 64 x 64 tiles.  One wave per SIMD issues every LDS-DMA piece, fragment read and
+// MFMA of its tile itself, so the time per K-tile is the wave's instruction stream (128 x 128: 8 pieces + 16 reads + 32
+// MFMAs = 0.75 us per K-tile even with hot weights: 17-22 us for 128 x 1536 x 1536); a quarter of the tile per wave and
+// four times the workgroups divide it.  tools/abl/small_tile_sweep.sh, us, 128 x 128 / 64 x 64 tiles: N = K = 1536, M = 256: 21.8 /
+// 9.1; 512: 22.0 / 9.8; 1024: 22.5 / 15.7; 2048 (192 tiles): 23.4 / 18.3; 4096 (384 tiles): 27.7 / 35.5.  N = K = 384, M = 1024:
+// 9.1 / 4.9; 4096: 9.4 / 5.4; 8192 (192 tiles): 9.9 / 7.5.
+static bool small_tile_64(const GemmBf16& g) {
+    // (Not the fused-loss launch: on the 64 x 64 instantiation one workgroup's sum (x-y)^2 came out a thread's worth short in
+    //  ~10 % of 200 identical launches - dY, the masked sum and every other output bit-identical; tools/abl/loss_repeat.py.
+    //  Unexplained from the ISA so far; the 128 x 128 instantiation is reproducible and stays.)
+    if (env().no_deep_small || g.loss.enabled || g.c_f32 || g.a_mode != OP_KC || g.b_mode != OP_KC || g.split_k != 1) return false;
+    return (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) <= env().small_tile_max;
+}
+
 // rows of g.colsum_part the launch gemm_bf16(g) makes will write: one per tile along M of the tile it picks
 int gemm_bf16_colsum_rows(const GemmBf16& g) {
     const int t = gemm_bf16_tile_big(g.M, g.N, g.loss.enabled ? 1 : g.split_k, g.b_mode == OP_KS || g.c_f32);
-    const int bm = g.loss.enabled ? (t ? 256 : 128) : (t ? 256 : 128);
+    const int bm = t ? 256 : (small_tile_64(g) ? 64 : 128);
     return (g.M + bm - 1) / bm;
 }
 
 int gemm_bf16_loss_parts(const GemmBf16& g) {
     const int t = gemm_bf16_tile_big(g.M, g.N, 1);
-    const int bm = t ? 256 : 128, bn = t ? 192 : 128;
+    const int sm = small_tile_64(g) ? 64 : 128;
+    const int bm = t ? 256 : sm, bn = t ? 192 : sm;
     return ((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
 }
 
@@ -682,13 +698,16 @@ int gemm_bf16(const GemmBf16& g, hipStream_t s) {
     if (g.loss.enabled) {
         const int t = gemm_bf16_tile_big(g.M, g.N, 1);
         if (t) return gemm_bf16_pipe(g, t >= 6 ? 6 : 1, s);       // 8-wave pipelined kernel, loss from the accumulators
+        if (small_tile_64(g)) return launch_cfg<64, 64, 2, 2>(g, s);
         return launch_cfg<128, 128, 2, 2>(g, s);
     }
     const int t = gemm_bf16_tile_big(g.M, g.N, g.split_k, g.b_mode == OP_KS || g.c_f32);
     switch (t) {
         case 3: return gemm_bf16_pipe(g, 1, s);               // 256 x 192, 8 waves, phase-pipelined, every wave loads
         case 6: return gemm_bf16_pipe(g, 6, s);               // 256 x 192, 8 waves, LDS-DMA issued by one wave per SIMD (default)
-        default: return launch_cfg<128, 128, 2, 2>(g, s);     // small problems: one-barrier double buffer
+        default:                                              // small problems: one-barrier double buffer
+            if (small_tile_64(g)) return launch_cfg<64, 64, 2, 2>(g, s);
+            return launch_cfg<128, 128, 2, 2>(g, s);
     }
 }
 

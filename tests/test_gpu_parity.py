@@ -774,6 +774,41 @@ def test_fused_step_with_two_blanked_slots_vs_oracle(precision, step_path):
     assert two > B                          # (6 of the 10 mask rows blank two slots)
 
 
+@pytest.mark.parametrize("S,E,B", [(3, 256, 4096), (3, 64, 128), (3, 512, 1024)])
+def test_training_forward_and_fused_loss_repeat_bit_for_bit(S, E, B):
+    """The training forward (loss fused into the last GEMM) launched 60 times on the same batch: the loss, both metric sums,
+    the dY workspace and every partial-sum row must come out identical every time.  (A 64 x 64 instantiation of the
+    fused-loss kernel once lost a thread's worth of one workgroup's sum (x-y)^2 in ~10 % of the launches; it is not
+    dispatched any more, tools/abl/loss_repeat.py.)"""
+    import ctypes as C
+    from codae import hip
+    from codae.train import HipEmbeddingTrainer
+    from oracle import dae_oracle as O
+    io = S * E
+    rng = np.random.default_rng(B)
+    N = 2 * B
+    data = rng.random((N, io), dtype=np.float32)
+    sched = O.layer_schedule(io, io, 2, 2, False, "embedding")
+    params = O.init_params(sched, rng)
+    bm, _, _ = O.corrupter_tables([{"size": E, "position": s * E} for s in range(S)], 1)
+    mtu = rng.integers(0, S, (N, 1)).astype(np.int32)
+    idx = torch.tensor(rng.permutation(N)[:B], dtype=torch.int32, device=DEV)
+    tr = HipEmbeddingTrainer(sched, torch.tensor(data), torch.tensor(bm).to(torch.uint8), torch.tensor(mtu), 1e-3, 1e-4, 1.0,
+                             max_batch=B, precision="bf16", device=DEV)
+    tr.load_params(params)
+    eng = tr.engine
+    eng.bias_parts.zero_()
+    batch = tr._batch(idx, 0)
+    hyper = eng.hyper(1e-3, 1e-4, 1.0, global_rows=B)
+    seen = set()
+    for i in range(60):
+        eng.zero_metric_sums()
+        hip.check(hip.lib().codae_step_forward_loss(eng._h, C.byref(eng.bufs), C.byref(batch), C.byref(hyper), None, hip.current_stream()))
+        sq, sqp, _, loss = eng.read_scalars()
+        seen.add((sq, sqp, loss, int(eng.dacts.view(torch.int16).to(torch.int64).sum()), float(eng.bias_parts.double().sum())))
+    assert len(seen) == 1, sorted(seen)[:4]
+
+
 def _fuzz_cases():
     rng = np.random.default_rng(2024)
     cases = []
