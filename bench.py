@@ -240,7 +240,7 @@ def main():
         tr.train_batch(idx_steps[st], run=0)
     barrier()
     kernel_events = not args.no_kernel_events and not args.graph
-    every = max(1, args.kernel_events_every)
+    every = max(1, min(args.kernel_events_every, args.steps))      # (at least one timed step carries the event pairs)
     if kernel_events:
         # A hipEvent pair costs 2-4 us of stream time INSIDE the timed region (it breaks back-to-back dispatch).  The
         # forward launches of a step (the class the roofline is quoted on) are dependent, gap-free kernels on one
@@ -265,6 +265,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     loss, gnorm = tr.last_loss_and_grad_norm()
+    step_path = "layers (bucketed backward + collectives)" if distributed else tr.engine.step_path(B)
     dp_info = None
     if distributed:
         dp_info = {"rccl_ranks": int(dist.get_world_size()), "backend": dist.get_backend(),
@@ -316,7 +317,7 @@ def main():
                        "mfma_roofline_frac_whole_step": (fps * value / world) / (peak * 1e12)},
             "final_loss": loss, "final_grad_norm": gnorm,
             "host_enqueue_ms_per_step": 1e3 * enqueue_s / args.steps,
-            "step_path": ("layers (bucketed backward + collectives)" if distributed else tr.engine.step_path(B)),
+            "step_path": step_path,
             "f32_parity": f32_parity,
         }
         if dp_info is not None:
