@@ -136,8 +136,10 @@ def check_kernel(name, pretty, insns):
     # check 1 runs over every K loop twice (wrap-around) and once over the whole kernel in address order (prologue, peeled
     # last K-tile, epilogue: straight-line code between the loops)
     walks = [insns[lo:hi + 1] * 2 for lo, hi in loops] + [insns]
+    # the 4-stage instantiations of the one-barrier kernel (last template argument 4) keep three K-tiles in flight too
+    deep = (not is_pipe) and len(args) >= 9 and args[8] == "4"
     for lo, hi in loops:
-        if is_pipe and not dbg:
+        if (is_pipe and not dbg) or deep:
             for a, o, ar in insns[lo:hi + 1]:
                 if o == "s_waitcnt" and re.search(r"vmcnt\(0\)", ar):
                     errs.append("s_waitcnt vmcnt(0) inside the K loop at 0x%x" % a)
