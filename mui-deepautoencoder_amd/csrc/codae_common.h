@@ -87,6 +87,7 @@ struct EnvToggles {
     int gemm_dbg = 0;            // CODAE_GEMM_DBG timing-only ablation builds of the forward form
     int wgrad_splitk = 0;        // CODAE_WGRAD_SPLITK > 0 forces the split
     int small_tile_max = 200;    // CODAE_SMALL_TILE_MAX: forward-form launches of up to this many 128 x 128 tiles run on 64 x 64 tiles
+    int small_stages = 4;        // CODAE_SMALL_STAGES=2: launches that cannot fill the chip keep the 2-stage double buffer
     int group_tile = -1;         // CODAE_GROUP_TILE: grouped weight gradients on 128 x 128 (0), 64 x 128 (1), 64 x 64 (2); -1 = automatic
     bool side_priority_set = false; int side_priority = 0;   // CODAE_SIDE_PRIORITY
     bool no_wt = false, single_stream = false, tail_on_side = false, no_fused_loss = false, flat_adam = false,

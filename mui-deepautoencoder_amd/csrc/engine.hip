@@ -41,6 +41,7 @@ void env_reload() {
     e.no_chain = getenv("CODAE_NO_CHAIN") != nullptr;
     e.no_deep_small = getenv("CODAE_NO_DEEP_SMALL") != nullptr;
     if (const char* k = getenv("CODAE_SMALL_TILE_MAX")) e.small_tile_max = atoi(k);
+    if (const char* k = getenv("CODAE_SMALL_STAGES")) e.small_stages = atoi(k) == 2 ? 2 : 4;
     g_env = e;
     g_env_loaded = true;
 }

@@ -154,7 +154,8 @@ __device__ __forceinline__ bf16x8 read_frag(const lds_char* tile, int t, int s, 
 // One output tile of one GEMM: the whole kernel body, so that the plain kernel (one GEMM per launch) and the grouped
 // kernel (several GEMMs per launch) share it.  wg / nwg: this workgroup's index among the nwg workgroups of ITS GEMM.
 // NS = operand stages in LDS.  2: the one-barrier double buffer (tile t + 1 requested while t is multiplied).  4: tiles up to
-// t + 3 in flight, for launches too small to fill the chip - a 128-row batch of a wide layer is 12 workgroups, each
+// t + 3 in flight (stock batch 128 at io 1536, whole step: 0.58 ms with 2 stages, 0.43 with 4, 0.44 with 8), for launches
+// too small to fill the chip - a 128-row batch of a wide layer is 12 workgroups, each
 // walking its 24 K-tiles of COLD weights one memory latency at a time (27 us for 0.6 GFLOP with NS = 2).
 template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, bool C_F32, bool LOSS, int NS = 2>
 __device__ __forceinline__ void gemm_bf16_tile(const GemmBf16& g, int tiles_n, int tiles_mn, int kt_total, int wg, int nwg,
@@ -573,7 +574,7 @@ int launch_cfg(const GemmBf16& g, hipStream_t s) {
                            tiles_m * tiles_n, kt_total);
     } else if (g.a_mode == OP_KC && g.b_mode == OP_KC) {
         // forward / data-gradient form of a launch that cannot fill the chip: four stages (see gemm_bf16_tile)
-        const bool deep = !g.c_f32 && nwg <= 256 && kt_total >= 6 && !env().no_deep_small;
+        const bool deep = !g.c_f32 && nwg <= 256 && kt_total >= 6 && !env().no_deep_small && env().small_stages >= 4;
         if (g.c_f32) LAUNCH(OP_KC, OP_KC, true);
         else if (deep)
             hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, OP_KC, OP_KC, false, false, 4>), grid, block, 0, s, g, tiles_n,
