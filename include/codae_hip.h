@@ -310,12 +310,14 @@ int codae_ranking_loss(const float* pred, const float* fmask, const int32_t* idx
  * validation rows at a time; *out += sum_b 1 - rank_b / (n_val - 1) (accumulates over the batches of an epoch).
  * inv_val [n_slots][n_val][E] = codae_gather_inventory_rows(inventory, val_idx), inv_val_norm its row norms;
  * val_pos [n_obs]: position of an observation in val_idx or -1 (a sample's own validation row is never counted: the
- * reference compares s[idx] with itself there), may be NULL; work: B * chunk floats; row_state: 32 * B bytes. */
+ * reference compares s[idx] with itself there), may be NULL.  Every slot's GEMM runs over the rows that blank THAT slot
+ * only (compacted on the device).  Workspaces: work B * chunk floats; row_state 32 * B bytes; perm_ws (n_slots * B +
+ * n_slots) int32; q_ws B * E floats. */
 int codae_ranking_loss_batched(const float* pred, int32_t B, int32_t io, int32_t n_slots, int32_t E, const int32_t* row_idx,
                                const int32_t* mask_id, const int32_t* mask_to_use, int32_t nb_run, int32_t run,
                                const uint8_t* mask_table, const float* inventory, const float* inventory_norm, int64_t n_obs,
                                const float* inv_val, const float* inv_val_norm, const int32_t* val_pos, int32_t n_val, float* work,
-                               int32_t chunk, void* row_state, double* out, void* stream);
+                               int32_t chunk, void* row_state, int32_t* perm_ws, float* q_ws, double* out, void* stream);
 /* dst[c][j][:] = inventory[c][val_idx[j]][:]  (inventory [n_slots][n_obs][E]) */
 int codae_gather_inventory_rows(const float* inventory, int64_t n_obs, int32_t E, int32_t n_slots, const int32_t* val_idx,
                                 int32_t n_val, float* dst, void* stream);

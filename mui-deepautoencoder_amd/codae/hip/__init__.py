@@ -99,7 +99,7 @@ PROTOTYPES = {
     "codae_row_norms": (C.c_int, [_P, _I64, _I32, _P, _P]),
     "codae_ranking_loss": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _I64, _P, _I32, _P, _P]),
     "codae_ranking_loss_batched": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _I32, _I32, _P, _P, _P, _I64, _P, _P, _P, _I32, _P,
-                                             _I32, _P, _P, _P]),
+                                             _I32, _P, _P, _P, _P, _P]),
     "codae_gather_inventory_rows": (C.c_int, [_P, _I64, _I32, _I32, _P, _I32, _P, _P]),
     "codae_step_path": (C.c_int, [_P, _P, _I32]),
     "codae_linear_f32": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),

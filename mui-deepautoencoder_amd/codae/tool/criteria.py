@@ -106,12 +106,14 @@ class RankingLoss:
         if self._work is None or self._work.numel() < B * chunk or self._rows.numel() < 8 * B:
             self._work = torch.empty(B * chunk, dtype=torch.float32, device=dev)
             self._rows = torch.empty(8 * B, dtype=torch.int32, device=dev)
+            self._perm = torch.empty(S * B + S, dtype=torch.int32, device=dev)
+            self._q = torch.empty(B * E, dtype=torch.float32, device=dev)
         m2u = corrupter.mask_to_use_i32
         with torch.cuda.device(dev):
             _check(_hip_lib().codae_ranking_loss_batched(
                 _ptr(pred), B, pred.shape[1], S, E, _ptr(row_idx), None, _ptr(m2u), m2u.shape[1], int(run),
                 _ptr(corrupter.mask_table_u8), _ptr(self._inv), _ptr(self._inv_norm), self._inv.shape[1],
-                _ptr(self._inv_val), _ptr(self._inv_val_norm), _ptr(self._val_pos), V, _ptr(self._work), chunk, _ptr(self._rows), _ptr(self._acc),
+                _ptr(self._inv_val), _ptr(self._inv_val_norm), _ptr(self._val_pos), V, _ptr(self._work), chunk, _ptr(self._rows), _ptr(self._perm), _ptr(self._q), _ptr(self._acc),
                 _stream()))
         self._keep = (pred, row_idx)             # (alive until the stream has consumed them)
 

@@ -109,6 +109,8 @@ struct GemmF32 {
     int64_t ld_relu;
     float* colsum_part;      // [ceil(M / 64)][N] column sums of the stored values per 64-row block (plain stores, summed in
                              // a fixed order by launch_bias_finish: deterministic bias gradients), or null
+    const int* m_dev;        // not null: the row count is min(M, *m_dev), read on the device (row tiles past it exit at once);
+                             // the grid is still sized for M
 };
 int gemm_f32(const GemmF32& g, hipStream_t s);
 inline int gemm_f32_colsum_rows(int M) { return (M + 63) / 64; }

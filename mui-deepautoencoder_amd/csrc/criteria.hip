@@ -185,7 +185,8 @@ __global__ __launch_bounds__(NT) void rank_prep_kernel(const float* __restrict__
                                                        const int32_t* __restrict__ mask_id, const int32_t* __restrict__ mask_to_use,
                                                        int nb_run, int run, const uint8_t* __restrict__ mask_table, int B, int io, int S,
                                                        int E, const float* __restrict__ inv, const float* __restrict__ inv_norm,
-                                                       int64_t n_obs, const int32_t* __restrict__ val_pos, RankRow* __restrict__ rs) {
+                                                       int64_t n_obs, const int32_t* __restrict__ val_pos, RankRow* __restrict__ rs,
+                                                       int32_t* __restrict__ perm, int32_t* __restrict__ counts) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -206,26 +207,42 @@ __global__ __launch_bounds__(NT) void rank_prep_kernel(const float* __restrict__
         // value with itself.  Here `own` and the GEMM's column for that row are summed in different orders, so that
         // column is skipped by position instead.
         o.self_col = val_pos ? val_pos[me] : -1;
-        o.pad[0] = o.pad[1] = o.pad[2] = 0;
+        // the rows of one slot, compacted (in arrival order: which GEMM row a sample lands on does not change its rank)
+        const int k = atomicAdd(&counts[c], 1);
+        perm[(int64_t)c * B + k] = b;
+        o.pad[0] = k; o.pad[1] = o.pad[2] = 0;
         rs[b] = o;
     }
 }
 
-// rows whose blanked slot is c: rank += #{ j < n : own > dots[b][j] / (|q| |inv_j|) }; one wave per row
+// compact rows of slot c (k < counts[c]; sample perm[c][k]): rank += #{ j < n : own > dots[k][j] / (|q| |inv_j|) }; one wave per row
 __global__ __launch_bounds__(NT) void rank_count_kernel(const float* __restrict__ dots, int64_t ld, int B, int n, int c, int v0,
-                                                        const float* __restrict__ val_norm, RankRow* __restrict__ rs) {
+                                                        const float* __restrict__ val_norm, RankRow* __restrict__ rs,
+                                                        const int32_t* __restrict__ perm, const int32_t* __restrict__ counts) {
     const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
-    if (b >= B) return;
+    const int k = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (k >= counts[c]) return;
+    const int b = perm[(int64_t)c * B + k];
     const RankRow me = rs[b];
-    if (me.slot != c) return;
-    const float* d = dots + (int64_t)b * ld;
+    const float* d = dots + (int64_t)k * ld;
     int cnt = 0;
     const int skip = me.self_col - v0;
     for (int j = lane; j < n; j += 64) cnt += (j != skip && me.own > d[j] / (me.qn * fmaxf(val_norm[j], 1e-8f))) ? 1 : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
     if (lane == 0) rs[b].rank = me.rank + cnt;
+}
+
+// q[k][:] = pred[perm[c][k]][cE:(c+1)E] for k < counts[c]: the slot's queries, contiguous (the GEMM's A operand)
+__global__ __launch_bounds__(NT) void rank_gather_q_kernel(const float* __restrict__ pred, int io, int E, int B, int c,
+                                                           const int32_t* __restrict__ perm, const int32_t* __restrict__ counts,
+                                                           float* __restrict__ q) {
+    const int n = counts[c];
+    const int64_t total = (int64_t)n * E;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < total; e += (int64_t)gridDim.x * NT) {
+        const int k = (int)(e / E), x = (int)(e - (int64_t)k * E);
+        q[e] = pred[(int64_t)perm[(int64_t)c * B + k] * io + (int64_t)c * E + x];
+    }
 }
 
 // *out += sum_b 1 - rank_b / (V - 1), rows added in index order (one workgroup: the same bits every run)
@@ -327,31 +344,40 @@ int codae_ranking_loss_batched(const float* pred, int32_t B, int32_t io, int32_t
                                const int32_t* mask_id, const int32_t* mask_to_use, int32_t nb_run, int32_t run,
                                const uint8_t* mask_table, const float* inventory, const float* inventory_norm, int64_t n_obs,
                                const float* inv_val, const float* inv_val_norm, const int32_t* val_pos, int32_t n_val, float* work,
-                               int32_t chunk, void* row_state, double* out, void* stream) {
+                               int32_t chunk, void* row_state, int32_t* perm_ws, float* q_ws, double* out, void* stream) {
     CODAE_REQUIRE(pred && row_idx && (mask_id || mask_to_use) && mask_table && inventory && inventory_norm && inv_val && inv_val_norm &&
-                      work && row_state && out, "ranking_loss_batched: null argument");
+                      work && row_state && perm_ws && q_ws && out, "ranking_loss_batched: null argument");
     CODAE_REQUIRE(B > 0 && n_slots > 0 && E > 0 && io == n_slots * E && n_val > 1 && n_obs > 0 && chunk > 0, "ranking_loss_batched: bad sizes");
     CODAE_REQUIRE(mask_id || (nb_run > 0 && run >= 0 && run < nb_run), "ranking_loss_batched: run %d outside [0, %d)", run, nb_run);
     hipStream_t s = (hipStream_t)stream;
     RankRow* rs = reinterpret_cast<RankRow*>(row_state);
+    int32_t* perm = perm_ws;                               // [n_slots][B]
+    int32_t* counts = perm_ws + (int64_t)n_slots * B;      // [n_slots]
+    CODAE_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)n_slots * sizeof(int32_t), s));
     const int rows_grid = (B + NT / 64 - 1) / (NT / 64);
     hipLaunchKernelGGL(rank_prep_kernel, dim3(rows_grid), dim3(NT), 0, s, pred, row_idx, mask_id, mask_to_use, nb_run, run, mask_table, B,
-                       io, n_slots, E, inventory, inventory_norm, n_obs, val_pos, rs);
+                       io, n_slots, E, inventory, inventory_norm, n_obs, val_pos, rs, perm, counts);
     CODAE_LAUNCH_CHECK();
-    for (int c = 0; c < n_slots; ++c)
+    // per slot: its rows' queries gathered, then one GEMM per chunk of validation rows over THOSE rows only (the row count
+    // stays on the device: the grid covers B rows, tiles past counts[c] return at once), then the compare-count pass
+    for (int c = 0; c < n_slots; ++c) {
+        hipLaunchKernelGGL(rank_gather_q_kernel, dim3(grid_for((int64_t)B * E / 4)), dim3(NT), 0, s, pred, io, E, B, c, perm, counts, q_ws);
+        CODAE_LAUNCH_CHECK();
         for (int v0 = 0; v0 < n_val; v0 += chunk) {
             const int n = n_val - v0 < chunk ? n_val - v0 : chunk;
             GemmF32 g{};
-            g.A = pred + (int64_t)c * E; g.a_rs = io; g.a_ks = 1;
+            g.A = q_ws; g.a_rs = E; g.a_ks = 1;
             g.B = inv_val + ((int64_t)c * n_val + v0) * E; g.b_rs = E; g.b_ks = 1;
             g.C = work; g.ldc = chunk;
             g.M = B; g.N = n; g.K = E;
+            g.m_dev = counts + c;
             int rc = gemm_f32(g, s);
             if (rc) return rc;
             hipLaunchKernelGGL(rank_count_kernel, dim3(rows_grid), dim3(NT), 0, s, work, (int64_t)chunk, B, n, c, v0,
-                               inv_val_norm + (int64_t)c * n_val + v0, rs);
+                               inv_val_norm + (int64_t)c * n_val + v0, rs, perm, counts);
             CODAE_LAUNCH_CHECK();
         }
+    }
     hipLaunchKernelGGL(rank_finish_kernel, dim3(1), dim3(NT), 0, s, rs, B, n_val, out);
     CODAE_LAUNCH_CHECK();
     return CODAE_OK;

@@ -90,6 +90,11 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmF32 g, bool a_vec, boo
     const int wr = w >> 1, wc = w & 1;
     const int li = lane & 31, kh = lane >> 5;
     const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+    if (g.m_dev != nullptr) {                 // (g is this kernel's own copy of the descriptor)
+        const int m = *g.m_dev;
+        if (m < g.M) g.M = m;
+    }
+    if (i0 >= g.M) return;
 
     f32x16 acc[2][2];
 #pragma unroll
