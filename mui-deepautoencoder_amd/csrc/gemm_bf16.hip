@@ -356,6 +356,12 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmBf16& g, int tiles_n, i
                             const float d = xv[k] - yv[k];
                             const float se = d * d;
                             sq += se;
+                            // Keeps sq a scalar chain.  Left alone, the compiler packs this accumulation with unrelated
+                            // values (v_pk_fma_f32 / v_pk_add_f32 with op_sel, the other lane carrying junk derived from
+                            // sqp); on the 64 x 64 instantiation one workgroup's sum then came out a thread's worth short in
+                            // ~10 % of 200 identical launches, every other output bit-identical (tools/abl/loss_repeat.py:
+                            // 5-28 distinct sums without this line, 1 with it).  The ISA reads correct; cause not found.
+                            asm volatile("" : "+v"(sq));
                             const uint32_t mb = ((k < 4 ? m.x : m.y) >> (8 * (k & 3))) & 0xff;
                             if (mb == 0) sqp += se;
                             gq[k] = -2.f * d * L.inv_n;
@@ -653,10 +659,7 @@ int gemm_bf16_tile_big(int M, int N, int split_k, bool k_strided = false) {
 // 9.1; 512: 22.0 / 9.8; 1024: 22.5 / 15.7; 2048 (192 tiles): 23.4 / 18.3; 4096 (384 tiles): 27.7 / 35.5.  N = K = 384, M = 1024:
 // 9.1 / 4.9; 4096: 9.4 / 5.4; 8192 (192 tiles): 9.9 / 7.5.
 static bool small_tile_64(const GemmBf16& g) {
-    // (Not the fused-loss launch: on the 64 x 64 instantiation one workgroup's sum (x-y)^2 came out a thread's worth short in
-    //  ~10 % of 200 identical launches - dY, the masked sum and every other output bit-identical; tools/abl/loss_repeat.py.
-    //  Unexplained from the ISA so far; the 128 x 128 instantiation is reproducible and stays.)
-    if (env().no_deep_small || g.loss.enabled || g.c_f32 || g.a_mode != OP_KC || g.b_mode != OP_KC || g.split_k != 1) return false;
+    if (env().no_deep_small || g.c_f32 || g.a_mode != OP_KC || g.b_mode != OP_KC || g.split_k != 1) return false;
     return (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) <= env().small_tile_max;
 }
 

@@ -774,12 +774,13 @@ def test_fused_step_with_two_blanked_slots_vs_oracle(precision, step_path):
     assert two > B                          # (6 of the 10 mask rows blank two slots)
 
 
-@pytest.mark.parametrize("S,E,B", [(3, 256, 4096), (3, 64, 128), (3, 512, 1024)])
+@pytest.mark.parametrize("S,E,B", [(3, 256, 4096), (3, 64, 128), (3, 512, 1024), (3, 512, 128), (3, 512, 8192)],
+                         ids=["64x64-768wg", "64x64-3wg", "64x64-192wg", "stock-batch", "c3-pipelined"])
 def test_training_forward_and_fused_loss_repeat_bit_for_bit(S, E, B):
     """The training forward (loss fused into the last GEMM) launched 60 times on the same batch: the loss, both metric sums,
-    the dY workspace and every partial-sum row must come out identical every time.  (A 64 x 64 instantiation of the
-    fused-loss kernel once lost a thread's worth of one workgroup's sum (x-y)^2 in ~10 % of the launches; it is not
-    dispatched any more, tools/abl/loss_repeat.py.)"""
+    the dY workspace and every partial-sum row must come out identical every time.  (The 64 x 64 instantiation of the
+    fused-loss kernel lost a thread's worth of one workgroup's sum (x-y)^2 in ~10 % of the launches until the compiler was
+    kept from packing that accumulation: gemm_bf16.hip, tools/abl/loss_repeat.py.)"""
     import ctypes as C
     from codae import hip
     from codae.train import HipEmbeddingTrainer
