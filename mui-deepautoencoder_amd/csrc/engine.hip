@@ -26,7 +26,7 @@ static bool g_env_loaded = false;
 void env_reload() {
     EnvToggles e;
     if (const char* t = getenv("CODAE_GEMM_TILE")) {
-        switch (t[0]) { case 's': e.gemm_tile = 0; break; case 'q': e.gemm_tile = 3; break; case 'x': e.gemm_tile = 6; break; default: break; }
+        switch (t[0]) { case 's': e.gemm_tile = 0; break; case 'q': e.gemm_tile = 3; break; case 'x': e.gemm_tile = 6; break; case 'm': e.gemm_tile = 7; break; default: break; }
     }
     if (const char* d = getenv("CODAE_GEMM_DBG")) e.gemm_dbg = atoi(d);
     if (const char* k = getenv("CODAE_WGRAD_SPLITK")) e.wgrad_splitk = atoi(k) > 0 ? atoi(k) : 0;

@@ -709,8 +709,13 @@ int gemm_bf16(const GemmBf16& g, hipStream_t s) {
     switch (t) {
         case 3: return gemm_bf16_pipe(g, 1, s);               // 256 x 192, 8 waves, phase-pipelined, every wave loads
         case 6: return gemm_bf16_pipe(g, 6, s);               // 256 x 192, 8 waves, LDS-DMA issued by one wave per SIMD (default)
+        case 7: return gemm_bf16_pipe(g, 7, s);              // (forced: 128 x 192 pipelined, forward form only)
         default:                                              // small problems: one-barrier double buffer
             if (small_tile_64(g)) return launch_cfg<64, 64, 2, 2>(g, s);
+            // between the 64 x 64 tiles and the 256 x 192 tile, forward / data-gradient form: the pipelined kernel on 128 x 192
+            // tiles (tools/bench_gemm_fwd.py, us, 128 x 128 one-barrier / 128 x 192 pipelined: 4096 x 1536 x 1536 28.3 / 21.9,
+            // 3000 x 1536 x 1536 26.4 / 19.8, 8192 x 768 x 768 17.9 / 14.6; same bits)
+            if (g.a_mode == OP_KC && g.b_mode == OP_KC && !g.c_f32 && g.split_k == 1 && !env().no_deep_small) return gemm_bf16_pipe(g, 7, s);
             return launch_cfg<128, 128, 2, 2>(g, s);
     }
 }

@@ -668,8 +668,25 @@ int launch_dbg(const GemmBf16& g, hipStream_t s) {
     return CODAE_OK;
 }
 
+// 128 x 192, 8 waves of 32 x 96 (forward / data-gradient form only: the k-strided half images need 96 or 128 columns):
+// for launches between the 64 x 64 tiles and the 256 x 192 tile - 4096 x 1536 is 256 of these, one per CU
+int launch_pipe_mid(const GemmBf16& g, hipStream_t s) {
+    constexpr int BM = 128, BN = 192;
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    CODAE_REQUIRE(g.a_mode == OP_KC && g.b_mode == OP_KC && !g.c_f32 && !g.loss.enabled && g.split_k == 1, "gemm_bf16: 128 x 192 tile is forward-form only");
+    CODAE_REQUIRE((int64_t)g.M * g.lda * 2 < (int64_t)1 << 32 && (int64_t)g.N * g.ldb * 2 < (int64_t)1 << 32, "gemm_bf16: operand larger than 4 GiB");
+    dim3 grid((unsigned)(tiles_m * tiles_n)), block(512);
+    if (g.relu_src != nullptr || g.colsum_part != nullptr)
+        hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, 4, 2, 4, OP_KC, OP_KC, false, 0, 2>), grid, block, 0, s, g, tiles_n, tiles_m * tiles_n, g.K / BK);
+    else
+        hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, 4, 2, 4, OP_KC, OP_KC, false, 0, 1>), grid, block, 0, s, g, tiles_n, tiles_m * tiles_n, g.K / BK);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
 // cfg 0: 256 x 192 with 4 waves; cfg 1: 256 x 192 with 8 waves
 int gemm_bf16_pipe(const GemmBf16& g, int cfg, hipStream_t s) {
+    if (cfg == 7) return launch_pipe_mid(g, s);
     if (g.dbg == 8 && g.loss.enabled) {          // stamped build of the fused-loss kernel (tools/timeline_loss.py)
         const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 191) / 192;
         hipLaunchKernelGGL((gemm_bf16_pipe_kernel<256, 192, 4, 2, 6, OP_KC, OP_KC, false, 8, 3>), dim3(tiles_m * tiles_n), dim3(512), 0, s, g,
