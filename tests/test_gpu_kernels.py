@@ -144,6 +144,27 @@ def test_linear_bf16_exact_integers(hip, tile, M, N, K, y_f32):
     assert np.array_equal(f64(y.float()), ref)
 
 
+@pytest.mark.parametrize("M,N,K", SHAPES_BF16 + [(3000, 1536, 1536)])
+def test_linear_bf16_mid_tile_exact_integers(hip, monkeypatch, M, N, K):
+    """The pipelined kernel's 128 x 192 instantiation (forward form only; taken automatically between the 64 x 64 and the
+    256 x 192 regime), forced here for every shape of the list, ragged ones included."""
+    monkeypatch.setenv("CODAE_GEMM_TILE", "m")
+    hip.lib().codae_reload_env()
+    try:
+        g = torch.Generator(device="cpu").manual_seed(M + 2 * N + 3 * K)
+        x, W, b = ints((M, K), g), ints((N, K), g), ints((N,), g)
+        xb, Wb = x.to(dev()).bfloat16(), W.to(dev()).bfloat16()
+        bd = b.to(dev())
+        y = torch.full((M, N), float("nan"), device=dev(), dtype=torch.bfloat16)
+        hip.check(hip.lib().codae_linear_bf16(hip.ptr(xb), hip.ptr(Wb), hip.ptr(bd), hip.ptr(y), 0, M, N, K, 1, hip.current_stream()))
+        sync()
+        ref = f64(torch.from_numpy(np.maximum(f64(x) @ f64(W).T + f64(b), 0)).bfloat16())
+        assert np.array_equal(f64(y.float()), ref)
+    finally:
+        monkeypatch.delenv("CODAE_GEMM_TILE", raising=False)
+        hip.lib().codae_reload_env()
+
+
 @pytest.mark.parametrize("M,N,K", SHAPES_BF16)
 def test_dgrad_bf16_exact_integers(hip, tile, M, N, K):
     # dx[M][K] = (dy[M][N] . W[N][K]) * [h > 0]; here the reduction dim is N (must be % 64)

@@ -810,6 +810,47 @@ def test_training_forward_and_fused_loss_repeat_bit_for_bit(S, E, B):
     assert len(seen) == 1, sorted(seen)[:4]
 
 
+@pytest.mark.parametrize("S,E,B", [(3, 512, 3000), (3, 256, 8192), (3, 512, 128)], ids=["mid-128x192", "mid-narrow", "small-64x64"])
+def test_small_and_mid_tiles_give_the_bits_of_the_128x128_kernel(monkeypatch, S, E, B):
+    """Three fused steps with the shape-dependent small-launch kernels (64 x 64 tiles with a 4-stage ring, the pipelined
+    kernel on 128 x 192 tiles, unsplit weight gradients) against the same steps with all of that off
+    (CODAE_NO_DEEP_SMALL=1: everything on the 128 x 128 one-barrier kernel).  Every kernel accumulates a tile's k range in
+    the same order, so activations, activation gradients and weight gradients must be bit-identical; bias gradients and
+    the metric sums differ only by how many rows a partial sum spans."""
+    from codae.train import HipEmbeddingTrainer
+    from oracle import dae_oracle as O
+    io = S * E
+    rng = np.random.default_rng(B + E)
+    N = B + 64
+    data = rng.random((N, io), dtype=np.float32)
+    sched = O.layer_schedule(io, io, 2, 2, False, "embedding")
+    params = O.init_params(sched, rng)
+    bm, _, _ = O.corrupter_tables([{"size": E, "position": s * E} for s in range(S)], 1)
+    mtu = rng.integers(0, S, (N, 1)).astype(np.int32)
+    idx = torch.tensor(rng.permutation(N)[:B], dtype=torch.int32, device=DEV)
+    outs = []
+    for new in (True, False):
+        if new:
+            monkeypatch.delenv("CODAE_NO_DEEP_SMALL", raising=False)
+        else:
+            monkeypatch.setenv("CODAE_NO_DEEP_SMALL", "1")
+        monkeypatch.setenv("CODAE_WGRAD_SPLITK", "1" if B <= 256 else "5")      # the same K split on both sides
+        tr = HipEmbeddingTrainer(sched, torch.tensor(data), torch.tensor(bm).to(torch.uint8), torch.tensor(mtu), 1e-3, 1e-4, 100.0,
+                                 max_batch=B, precision="bf16", device=DEV)
+        tr.load_params(params)
+        assert tr.engine.step_path(B) == "layers"
+        tr.train_batch(idx, run=0)
+        eng = tr.engine
+        nw = eng.b_off[0]
+        outs.append((eng.acts.clone(), eng.dacts.clone(), eng.grads[:nw].clone(), eng.grads[nw:].clone(), eng.read_scalars()))
+    (aa, da, ga, ba, sa), (ab, db, gb, bb, sb) = outs
+    assert torch.equal(da, db), "activation gradients"
+    assert torch.equal(ga, gb), "weight gradients"
+    assert torch.equal(aa, ab), "saved activations"
+    assert float((ba - bb).abs().max()) <= 1e-5 * float(bb.abs().max())
+    assert abs(sa[3] - sb[3]) <= 1e-6 * abs(sb[3])
+
+
 def _fuzz_cases():
     rng = np.random.default_rng(2024)
     cases = []
