@@ -111,6 +111,9 @@ struct GemmF32 {
                              // a fixed order by launch_bias_finish: deterministic bias gradients), or null
     const int* m_dev;        // not null: the row count is min(M, *m_dev), read on the device (row tiles past it exit at once);
                              // the grid is still sized for M
+    int split_k;             // > 1: K is cut into split_k ranges of whole 32-deep tiles (grid.z); range z writes its partial
+                             // product to C + z * M * ldc (fp32 slabs, reduced in slab order by reduce_slabs_kernel); no
+                             // bias / ReLU / column sums then
 };
 int gemm_f32(const GemmF32& g, hipStream_t s);
 inline int gemm_f32_colsum_rows(int M) { return (M + 63) / 64; }

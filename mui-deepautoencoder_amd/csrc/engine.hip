@@ -160,6 +160,19 @@ struct GroupScope {
 // Split-K factor of the weight-gradient GEMM dW[N][K] = dA^T H over `rows` batch rows: enough
 // K-slices that the output tiles cover the chip once (256 x 192 tiles), or ~2 workgroups per CU
 // with the 128 x 128 tile when the big one cannot fill it.  Must agree with gemm_bf16_tile_big.
+// exact-fp32 weight gradient (128 x 128 tiles, two workgroups per CU): enough K ranges for ~1.5 workgroups per CU - a
+// 1536 x 1536 gradient is 144 tiles, whose 8192-row reductions were the critical path of the whole backward (0.97 ms per
+// layer on the side stream); never for batches of <= 1024 rows
+int choose_split_k_f32(int N, int K, int rows) {
+    if (env().wgrad_splitk > 0) return env().wgrad_splitk <= rows / 32 ? env().wgrad_splitk : 1;
+    if (rows <= 1024) return 1;
+    const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+    int s = (384 + tiles / 2) / tiles;
+    if (s > 8) s = 8;
+    if (s > rows / 256) s = rows / 256;
+    return s < 1 ? 1 : s;
+}
+
 int choose_split_k(int N, int K, int rows) {
     const int kt = rows / 64;
     int s;
@@ -361,12 +374,27 @@ int run_wgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, hi
         ProfScope prof(e, CODAE_K_GEMM_WGRAD, s);
         return gemm_bf16(g, s);
     }
-    ProfScope prof(e, CODAE_K_GEMM_WGRAD, s);
     GemmF32 g{};
     g.A = reinterpret_cast<const float*>(dact_ptr(e, b, l)); g.a_rs = 1; g.a_ks = N;
     g.B = reinterpret_cast<const float*>(act_ptr(e, b, l)); g.b_rs = 1; g.b_ks = K;
     g.C = dW; g.ldc = K;
     g.M = N; g.N = K; g.K = rows;
+    int S = e->split_k[l];
+    if (S > rows / 32) S = rows / 32;
+    if (S > 1 && b->slabs != nullptr) {
+        // K split over workgroups: fp32 slabs, added in slab order by the reduce (same fp32 arithmetic, another summation order)
+        float* slab = reinterpret_cast<float*>(reinterpret_cast<char*>(b->slabs) + (int64_t)slot * e->slab_bytes);
+        g.C = slab; g.split_k = S;
+        int rc;
+        {
+            ProfScope prof(e, CODAE_K_GEMM_WGRAD, s);
+            rc = gemm_f32(g, s);
+        }
+        if (rc) return rc;
+        ProfScope prof(e, CODAE_K_SLAB_REDUCE, s);
+        return launch_reduce_slabs(slab, S, (int64_t)N * K, dW, (int64_t)N * K, nullptr, s);
+    }
+    ProfScope prof(e, CODAE_K_GEMM_WGRAD, s);
     return gemm_f32(g, s);
 }
 
@@ -634,6 +662,7 @@ int codae_create(const codae_spec* spec, codae_handle* out) {
     for (int l = 0; l < e->L; ++l) {
         int s = 1;
         if (e->prec == CODAE_PREC_BF16) s = choose_split_k(e->out[l], e->in[l], e->max_rows);
+        else s = choose_split_k_f32(e->out[l], e->in[l], e->max_rows);
         e->split_k.push_back(s);
         if (s > 1) {
             const int64_t bytes = (int64_t)s * e->in[l] * e->out[l] * 4;
