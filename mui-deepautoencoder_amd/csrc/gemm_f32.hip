@@ -83,9 +83,10 @@ template <bool A_KC, bool B_KC>
 //  no faster than two: 349 vs 346 us for the 8192 x 1536 x 1536 forward form.)
 __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmF32 g, bool a_vec, bool b_vec) {
     constexpr int LDA = LDS_LD<A_KC>, LDB = LDS_LD<B_KC>;
-    __shared__ __attribute__((aligned(16))) float smem[BK * 132 * 2];
-    float* As = smem;
-    float* Bs = smem + BK * 132;
+    // two operand buffers: tile k + 1 is stored into the other one right after tile k is multiplied, so ONE barrier per
+    // K-tile separates "everybody has finished reading buffer b" from "somebody overwrites buffer b" (it was store /
+    // barrier / multiply / barrier on a single buffer: parity-mode step 10.4 ms)
+    __shared__ __attribute__((aligned(16))) float smem[2][BK * 132 * 2];
 
     const int t = threadIdx.x;
     const int lane = t & 63, w = t >> 6;
@@ -119,13 +120,16 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmF32 g, bool a_vec, boo
     float ra[16], rb[16];
     load_tile<A_KC>(ra, g.A, g.a_rs, g.a_ks, i0, k_begin, g.M, k_end, a_vec, t);
     load_tile<B_KC>(rb, g.B, g.b_rs, g.b_ks, j0, k_begin, g.N, k_end, b_vec, t);
+    store_tile<A_KC>(smem[0], ra, t);
+    store_tile<B_KC>(smem[0] + BK * 132, rb, t);
+    __syncthreads();
 
+    int cur = 0;
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-        __syncthreads();
-        store_tile<A_KC>(As, ra, t);
-        store_tile<B_KC>(Bs, rb, t);
-        __syncthreads();
-        if (k0 + BK < k_end) {
+        const float* As = smem[cur];
+        const float* Bs = smem[cur] + BK * 132;
+        const bool more = k0 + BK < k_end;
+        if (more) {
             load_tile<A_KC>(ra, g.A, g.a_rs, g.a_ks, i0, k0 + BK, g.M, k_end, a_vec, t);
             load_tile<B_KC>(rb, g.B, g.b_rs, g.b_ks, j0, k0 + BK, g.N, k_end, b_vec, t);
         }
@@ -141,6 +145,12 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmF32 g, bool a_vec, boo
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+        if (more) {
+            store_tile<A_KC>(smem[cur ^ 1], ra, t);
+            store_tile<B_KC>(smem[cur ^ 1] + BK * 132, rb, t);
+        }
+        __syncthreads();
+        cur ^= 1;
     }
 
     // epilogue: D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
