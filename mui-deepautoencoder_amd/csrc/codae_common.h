@@ -230,6 +230,8 @@ int launch_transpose_bf16(const bf16_t* src, bf16_t* dst, int n, const int64_t* 
                           hipStream_t s);
 int gemm_bf16_timeline(unsigned long long* host_out, int n_wg);   // CODAE_GEMM_DBG=8 stamps
 // sumsq != null: += sum out^2 (slot-scattered)
+int launch_reduce_slabs_epi(const float* slabs, int n_slabs, int64_t stride, int M, int N, float* C, int64_t ldc, const float* bias,
+                            int relu, const float* relu_src, int64_t ld_relu, float* colsum_part, hipStream_t s);
 int launch_reduce_slabs(const float* slabs, int n_slabs, int64_t slab_stride, float* out, int64_t n, double* sumsq,
                         hipStream_t s);
 // parts != null: SQ_FULL += sum parts[i][0], SQ_PARTIAL += sum parts[i][1] (fixed order) and the step's loss from

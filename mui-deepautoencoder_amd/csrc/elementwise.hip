@@ -434,6 +434,54 @@ __global__ __launch_bounds__(NT) void reduce_slabs_kernel(const float* __restric
     }
 }
 
+
+// Split-K fp32 GEMM, second stage WITH the GEMM's epilogue (exact-fp32 forward / data-gradient launches of a small batch:
+// 128 rows of a 1536-wide layer are 12 workgroups walking 48 K-tiles each - 124 / 178 us per launch; split over K they
+// fill the chip and this kernel finishes them): C[i][j] = epi(sum_z slabs[z][i][j]), epi = + bias, ReLU, * [relu_src > 0];
+// colsum_part[i / 64][j] = sum of the stored values over the block's 64 rows (the next bias gradient's partial rows, as
+// gemm_f32 writes them).  One workgroup = 64 rows x 64 columns: thread -> 4 columns x 4 rows (16 apart).
+__global__ __launch_bounds__(NT) void reduce_slabs_epi_kernel(const float* __restrict__ slabs, int n_slabs, int64_t stride, int M, int N,
+                                                              float* __restrict__ C, int64_t ldc, const float* __restrict__ bias, int relu,
+                                                              const float* __restrict__ relu_src, int64_t ld_relu,
+                                                              float* __restrict__ colsum_part) {
+    __shared__ float red[16][64 + 4];
+    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int j = blockIdx.x * 64 + cg * 4;
+    const int i0 = blockIdx.y * 64;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (j < N) {                                               // (N % 4 == 0: checked by the launcher)
+        float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias != nullptr) bj = *reinterpret_cast<const float4*>(bias + j);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + rg + 16 * q;
+            if (i >= M) break;
+            float4 a = *reinterpret_cast<const float4*>(slabs + (int64_t)i * N + j);
+            for (int z = 1; z < n_slabs; ++z) {
+                const float4 b = *reinterpret_cast<const float4*>(slabs + z * stride + (int64_t)i * N + j);
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+            a.x += bj.x; a.y += bj.y; a.z += bj.z; a.w += bj.w;
+            if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+            if (relu_src != nullptr) {
+                const float4 h = *reinterpret_cast<const float4*>(relu_src + (int64_t)i * ld_relu + j);
+                a.x = h.x > 0.f ? a.x : 0.f; a.y = h.y > 0.f ? a.y : 0.f; a.z = h.z > 0.f ? a.z : 0.f; a.w = h.w > 0.f ? a.w : 0.f;
+            }
+            *reinterpret_cast<float4*>(C + (int64_t)i * ldc + j) = a;
+            cs[0] += a.x; cs[1] += a.y; cs[2] += a.z; cs[3] += a.w;
+        }
+    }
+    if (colsum_part != nullptr) {
+        red[rg][cg * 4 + 0] = cs[0]; red[rg][cg * 4 + 1] = cs[1]; red[rg][cg * 4 + 2] = cs[2]; red[rg][cg * 4 + 3] = cs[3];
+        __syncthreads();
+        if (threadIdx.x < 64 && blockIdx.x * 64 + (int)threadIdx.x < N) {
+            float t = 0.f;
+            for (int r = 0; r < 16; ++r) t += red[r][threadIdx.x];
+            colsum_part[(int64_t)blockIdx.y * N + blockIdx.x * 64 + threadIdx.x] = t;
+        }
+    }
+}
+
 // parts[block][c] = sum over the block's 64 rows of src[r][c]   (bias gradient of a dense dy, first stage)
 __global__ __launch_bounds__(NT) void colsum_parts_f32_kernel(const float* __restrict__ src, int M, int N,
                                                               float* __restrict__ parts) {
@@ -874,6 +922,17 @@ int launch_reduce_slabs(const float* slabs, int n_slabs, int64_t stride, float* 
                         hipStream_t s) {
     CODAE_REQUIRE(slabs && out && n_slabs >= 1 && n > 0, "reduce_slabs: bad args");
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, s, slabs, n_slabs, stride, out, n, sumsq);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+int launch_reduce_slabs_epi(const float* slabs, int n_slabs, int64_t stride, int M, int N, float* C, int64_t ldc, const float* bias,
+                            int relu, const float* relu_src, int64_t ld_relu, float* colsum_part, hipStream_t s) {
+    CODAE_REQUIRE(slabs && C && n_slabs >= 1 && M > 0 && N > 0 && N % 4 == 0 && ldc % 4 == 0 && (relu_src == nullptr || ld_relu % 4 == 0) &&
+                      a16(slabs) && a16(C) && (bias == nullptr || a16(bias)) && (relu_src == nullptr || a16(relu_src)),
+                  "reduce_slabs_epi: bad args");
+    hipLaunchKernelGGL(reduce_slabs_epi_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(NT), 0, s, slabs, n_slabs, stride, M, N, C, ldc, bias,
+                       relu, relu_src, ld_relu, colsum_part);
     CODAE_LAUNCH_CHECK();
     return CODAE_OK;
 }

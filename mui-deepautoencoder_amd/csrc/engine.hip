@@ -320,6 +320,27 @@ int run_wgrad_grouped(const codae_engine* e, const codae_buffers* b, int rows, b
     return CODAE_OK;
 }
 
+// Exact-fp32 GEMM of a launch too small to fill the chip (forward / data gradient of a small batch): K split over
+// workgroups into fp32 slabs (slab slot 2: the caller's stream), then the reduce that applies the GEMM's epilogue.  Same
+// fp32 arithmetic in another summation order.  3 x 512 at batch 128, whole parity-mode step: 3.09 -> see DESIGN.md.
+int gemm_f32_small(const codae_engine* e, const codae_buffers* b, const GemmF32& g, hipStream_t s) {
+    const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
+    const int kt = (g.K + 31) / 32;
+    int S = tiles >= 128 ? 1 : (256 + tiles / 2) / tiles;
+    if (S > kt / 4) S = kt / 4;                       // at least 4 K-tiles per range
+    if (S > 16) S = 16;
+    while (S > 1 && (int64_t)S * g.M * g.N * 4 > e->slab_bytes) --S;
+    if (S <= 1 || b->slabs == nullptr || e->cfg.no_deep_small || (g.N % 4) != 0 || (g.ldc % 4) != 0 || g.m_dev != nullptr ||
+        (g.relu_src != nullptr && (g.ld_relu % 4) != 0))
+        return gemm_f32(g, s);
+    float* slab = reinterpret_cast<float*>(reinterpret_cast<char*>(b->slabs) + 2 * e->slab_bytes);
+    GemmF32 p = g;
+    p.C = slab; p.ldc = g.N; p.bias = nullptr; p.relu = 0; p.relu_src = nullptr; p.ld_relu = 0; p.colsum_part = nullptr; p.split_k = S;
+    int rc = gemm_f32(p, s);
+    if (rc) return rc;
+    return launch_reduce_slabs_epi(slab, S, (int64_t)g.M * g.N, g.M, g.N, g.C, g.ldc, g.bias, g.relu, g.relu_src, g.ld_relu, g.colsum_part, s);
+}
+
 // y = act(x W^T + b) for layer l
 int run_linear(const codae_engine* e, const codae_buffers* b, int l, const void* x, void* y, bool y_f32, int rows,
                hipStream_t s) {
@@ -341,7 +362,7 @@ int run_linear(const codae_engine* e, const codae_buffers* b, int l, const void*
     g.C = reinterpret_cast<float*>(y); g.ldc = N;
     g.M = rows; g.N = N; g.K = K;
     g.bias = b->params + e->b_off[l]; g.relu = e->relu[l];
-    return gemm_f32(g, s);
+    return gemm_f32_small(e, b, g, s);
 }
 
 // dW_l = dA_l^T act[l] on stream s.  bf16: split-K partial slabs (slab buffer `slot`), then the reduce on the same stream.
@@ -437,7 +458,7 @@ int run_dgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, fl
         g.colsum_part = part_ptr(e, b, l - 1);
         e->parts_pending[l - 1] = gemm_f32_colsum_rows(rows);
     }
-    return gemm_f32(g, s);
+    return gemm_f32_small(e, b, g, s);
 }
 
 // Wt_l [in][out] <- W_l [out][in] (bf16) for every layer that has a data gradient (l >= 1)
@@ -668,6 +689,11 @@ int codae_create(const codae_spec* spec, codae_handle* out) {
             const int64_t bytes = (int64_t)s * e->in[l] * e->out[l] * 4;
             if (bytes > e->slab_bytes) e->slab_bytes = bytes;
         }
+    }
+    if (e->prec == CODAE_PREC_F32 && e->max_rows <= 512) {
+        // room for the split-K slabs of a small batch's forward / data-gradient launches (gemm_f32_small)
+        const int64_t bytes = (int64_t)16 * e->max_rows * e->maxw * 4;
+        if (bytes > e->slab_bytes) e->slab_bytes = bytes;
     }
     *out = e;
     return CODAE_OK;
