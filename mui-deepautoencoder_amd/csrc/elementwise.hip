@@ -536,7 +536,14 @@ __global__ __launch_bounds__(NT) void bias_finish_kernel(BiasFinishJobs jobs, do
         const float* p = jobs.parts[j] + c;
         float s = 0.f;
         int r = 0;
-        for (; r + 8 <= R; r += 8) {                // 8 independent loads in flight, added in row order
+        for (; r + 32 <= R; r += 32) {              // 32 independent loads in flight (C3: all of a column's rows in ONE trip to
+            float v[32];                             // memory; 8 at a time was four dependent trips, 9.5 us), added in row order
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = p[(int64_t)(r + u) * N];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) s += v[u];
+        }
+        for (; r + 8 <= R; r += 8) {
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(r + u) * N];
