@@ -154,8 +154,9 @@ def main():
     ap.add_argument("--embedding", type=int, default=None)
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-f32-parity", action="store_true", help="skip the exact-fp32 (parity mode) leg")
-    ap.add_argument("--kernel-events-every", type=int, default=4,
-                    help="record per-launch hipEvent pairs in every n-th timed step only")
+    ap.add_argument("--kernel-events-every", type=int, default=16,
+                    help="record per-launch hipEvent pairs in every n-th timed step only (a sampled C3 step carries ~60 event "
+                         "records: every 4th step cost 4 %% of the reported rate, every 16th 0.7 %%, none 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not record per-launch hipEvents in the timed region (roofline then null)")
