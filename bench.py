@@ -240,8 +240,25 @@ def main():
     for st in range(args.warmup):
         tr.train_batch(idx_steps[st], run=0)
     barrier()
+    # Ramp-up guard (untimed, on top of the W warm-up steps the caller asked for): a process whose first kernels have
+    # just run is not in steady state - code objects of kernels that only the 2nd step needs, the power state after an
+    # idle lease (tools/cold_start.py).  Extra steps run one at a time until two consecutive ones
+    # agree within 10 %, at most MAX_EXTRA; they re-use the warm-up batches and are reported as `warmup_effective`.
+    extra, prev_ms, ramp_ms = 0, None, []
+    MAX_EXTRA = 12
+    while extra < MAX_EXTRA:
+        ts = time.perf_counter()
+        tr.train_batch(idx_steps[extra % max(1, args.warmup or 1)], run=0)
+        barrier()
+        ms = 1e3 * (time.perf_counter() - ts)
+        ramp_ms.append(ms)
+        extra += 1
+        if prev_ms is not None and abs(ms - prev_ms) <= 0.10 * min(ms, prev_ms) and extra >= 3:
+            break
+        prev_ms = ms
     kernel_events = not args.no_kernel_events and not args.graph
-    every = max(1, min(args.kernel_events_every, args.steps))      # (at least one timed step carries the event pairs)
+    # at least three timed steps carry the per-launch event pairs (mean != min in by_kernel), spread over the region
+    every = max(1, min(args.kernel_events_every, args.steps // 3 if args.steps >= 3 else 1))
     if kernel_events:
         # A hipEvent pair costs 2-4 us of stream time INSIDE the timed region (it breaks back-to-back dispatch).  The
         # forward launches of a step (the class the roofline is quoted on) are dependent, gap-free kernels on one
@@ -253,9 +270,16 @@ def main():
         tr.engine.profile_begin(classes, max_records=64 * (args.steps // every + 2), every=every)
         if tr.dp is not None:
             tr.dp.time_waits(every)
+    step_times = [] if os.environ.get("BENCH_STEP_TIMES") == "1" else None      # diagnosis only: a sync per timed step
     t0 = time.perf_counter()
+    enq_marks = []
     for st in range(args.warmup, total_steps):
         tr.train_batch(idx_steps[st], run=0)
+        if len(enq_marks) < 8:
+            enq_marks.append(1e3 * (time.perf_counter() - t0))
+        if step_times is not None:
+            torch.cuda.synchronize()
+            step_times.append(1e3 * (time.perf_counter() - t0))
     enqueue_s = time.perf_counter() - t0      # host time to ENQUEUE the timed steps (no device sync yet)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -308,6 +332,7 @@ def main():
             "metric": "training samples/sec at 3x512-dim input, batch 8192" if (slots, emb, B) == (S, E, BATCH)
                       else "training samples/sec at %dx%d-dim input, batch %d" % (slots, emb, B),
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "warmup_effective": args.warmup + extra,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "embedding.yaml topology: %d slots x %d (io %d), z=io, 4+4 layers -> 10 x Linear(%d,%d); "
@@ -318,15 +343,17 @@ def main():
                        "mfma_roofline_frac_whole_step": (fps * value / world) / (peak * 1e12)},
             "final_loss": loss, "final_grad_norm": gnorm,
             "host_enqueue_ms_per_step": 1e3 * enqueue_s / args.steps,
+            "host_enqueue_done_ms_first_steps": enq_marks, "ramp_up_step_ms": ramp_ms,
             "step_path": step_path,
             "f32_parity": f32_parity,
+            **({"step_done_ms": step_times} if step_times is not None else {}),
         }
         if dp_info is not None:
             out["data_parallel"] = dp_info
         roof = None
         if prof:
             by = {}
-            sampled_steps = max(1, args.steps // every)
+            sampled_steps = max(1, args.steps // every)      # (steps every, 2 every, ... carry the pairs)
             gemm_flops = 2.0 * B * io * io
             for name, ms in prof.items():
                 mean_ms = float(np.mean(ms))
@@ -336,10 +363,15 @@ def main():
                     by[name]["tflops"] = gemm_flops / (mean_ms * 1e-3) / 1e12
             # ("loss" in the fused bf16 step = the LAST forward GEMM with the MSE loss in its epilogue: GEMM flops
             # plus a gather of the 50 MB target rows, so it is listed apart from the plain forward launches)
-            # The forward GEMM class (the "3-slot x 512 encoder GEMM" of BASELINE.json) is the kernel the
-            # roofline is quoted on: its launches run alone on the chip.  The dgrad and wgrad launches of one
-            # layer run CONCURRENTLY on two streams, so their per-launch event times overlap (by_kernel keeps them).
-            dom = "gemm_fwd" if "gemm_fwd" in by else max(by, key=lambda k: by[k]["ms_per_step"])
+            # `roofline` is quoted on the DOMINANT kernel class: the GEMM class with the largest share of the step's
+            # time (by_kernel[..].ms_per_step), not the best one.  `roofline_fwd` keeps the forward class (the "3-slot x
+            # 512 encoder GEMM" BASELINE.json's target names) and `roofline_step` the whole step (algorithmic flops of the
+            # step / wall time per step).  Classes that run concurrently on two streams (deferred-wgrad path: none; DP
+            # path: dgrad beside wgrad) have overlapping event times, which by_kernel keeps as measured.
+            gemm_classes = [k for k in by if k.startswith("gemm_")]
+            dom = max(gemm_classes, key=lambda k: by[k]["ms_per_step"]) if gemm_classes else max(by, key=lambda k: by[k]["ms_per_step"])
+            if "chain" in by:
+                dom = "chain"
             if dom == "chain":
                 # narrow stack: the persistent fused chain is the step's dominant kernel.  Its arithmetic is tiny
                 # (forward + data gradients); what it has to MOVE through HBM per launch: the gathered batch (fp32), every
@@ -372,8 +404,14 @@ def main():
             if roof is None:
                 roof = {"bound": "mfma", "kernel": dom, "achieved": by[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
                         "frac": by[dom]["tflops"] / peak, "traffic": traffic, "traffic_source": traffic_src,
-                        "flops_per_launch": gemm_flops, "by_kernel": by}
+                        "flops_per_launch": gemm_flops * by[dom].get("gemms_per_launch", 1), "by_kernel": by}
+                if "gemm_fwd" in by:
+                    out["roofline_fwd"] = {"bound": "mfma", "kernel": "gemm_fwd", "achieved": by["gemm_fwd"]["tflops"], "peak": peak,
+                                           "unit": "TFLOP/s", "frac": by["gemm_fwd"]["tflops"] / peak}
         out["roofline"] = roof
+        step_tf = fps * value / world / 1e12
+        out["roofline_step"] = {"bound": "mfma", "achieved": step_tf, "peak": peak, "unit": "TFLOP/s", "frac": step_tf / peak,
+                                "note": "algorithmic flops of the whole step (29 GEMMs' worth at C3) / wall time per step"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(schedule, data, blank, io, slots, B)
         else:

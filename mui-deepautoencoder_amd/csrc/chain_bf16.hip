@@ -384,7 +384,7 @@ __global__ __launch_bounds__(CH_NT, 1) void chain_step_kernel(ChainArgs a_by_val
                         const float d = live ? xs[k] - yv[k] : 0.f;
                         const float se = d * d;
                         sq += se;
-                        asm volatile("" : "+v"(sq));     // scalar chain: see the fused-loss epilogue of gemm_bf16.hip
+                        asm volatile("" : "+v"(sq));     // scalar chain, never packed with op_sel half swaps: gemm_bf16.hip, DESIGN.md 5d
                         sqp += ((m >> (8 * k)) & 0xffu) == 0 ? se : 0.f;
                         gq[k] = live ? -2.f * d * a->inv_n : 0.f;        // (+0 in the pad rows, like the per-layer kernels)
                     }

@@ -35,6 +35,13 @@ namespace {
 
 constexpr int BK = 64;
 
+#if defined(CODAE_DBG_5D)
+// section 5d probe builds only (tools/abl/probe_5d.py): bit 0 = no scalar-chain guard in the fused-loss epilogue, bit 1 = every
+// thread's {sq, sqp} of the 64 x 64 fused-loss tile dumped here before the cross-lane reduction
+constexpr int DBG5D_WGS = 1024;
+__device__ float g_dbg5d[DBG5D_WGS * 256 * 2];
+#endif
+
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(1))) const void gvoid;
 
@@ -288,6 +295,10 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmBf16& g, int tiles_n, i
         const int j = j0 + c * 8;
         float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float sq = 0.f, sqp = 0.f;
+#if defined(CODAE_DBG_5D) && (CODAE_DBG_5D & 4)
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        f32x2_t sq2 = {0.f, 0.f};
+#endif
         bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
         constexpr int ITER = (HR + RL - 1) / RL;                // rows per thread per pass
         const int* rowinfo = reinterpret_cast<const int*>(smem_raw + 2 * BUF_BYTES);
@@ -351,17 +362,52 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmBf16& g, int tiles_n, i
                         const float xv[8] = {xa[it].x, xa[it].y, xa[it].z, xa[it].w, xb[it].x, xb[it].y, xb[it].z, xb[it].w};
                         const float yv[8] = {ya[0], ya[1], ya[2], ya[3], yb[0], yb[1], yb[2], yb[3]};
                         float gq[8];
+#if defined(CODAE_DBG_5D) && (CODAE_DBG_5D & 4)
+                        // probe variant: the sum of squares as an explicit packed chain WITHOUT half swaps (even / odd lanes
+                        // accumulate apart, v_pk_fma_f32 with default op_sel); folded after the loop
+                        {
+                            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+                            for (int k = 0; k < 8; k += 2) {
+                                f32x2_t d2 = {xv[k] - yv[k], xv[k + 1] - yv[k + 1]};
+#if (CODAE_DBG_5D & 8)
+                                // in-place form the compiler chose in the failing build: dst = src0 = src1, accumulator as src2
+                                asm volatile("v_pk_fma_f32 %0, %0, %0, %1" : "+v"(d2) : "v"(sq2));
+                                sq2 = d2;
+#elif (CODAE_DBG_5D & 16)
+                                // the failing build's FIRST op: squares of d added to the HALF-SWAPPED src2 (op_sel on src2)
+                                if (k == 0) {
+                                    f32x2_t se2 = d2 * d2, r2;
+                                    asm volatile("v_pk_fma_f32 %0, %1, %1, %2 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "=v"(r2) : "v"(d2), "v"(se2));
+                                    sq2 += r2 * 0.5f;
+                                } else {
+                                    asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(sq2) : "v"(d2));
+                                }
+#else
+                                asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(sq2) : "v"(d2));
+#endif
+                            }
+                        }
+#endif
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
                             const float d = xv[k] - yv[k];
                             const float se = d * d;
+#if !(defined(CODAE_DBG_5D) && (CODAE_DBG_5D & 4))
                             sq += se;
-                            // Keeps sq a scalar chain.  Left alone, the compiler packs this accumulation with unrelated
-                            // values (v_pk_fma_f32 / v_pk_add_f32 with op_sel, the other lane carrying junk derived from
-                            // sqp); on the 64 x 64 instantiation one workgroup's sum then came out a thread's worth short in
-                            // ~10 % of 200 identical launches, every other output bit-identical (tools/abl/loss_repeat.py:
-                            // 5-28 distinct sums without this line, 1 with it).  The ISA reads correct; cause not found.
+#endif
+                            // Keeps sq a scalar chain.  Left alone, the SLP vectorizer packs this
+                            // accumulation into v_pk_fma_f32 / v_pk_add_f32 pairs and folds the lane shuffle into op_sel; one of
+                            // them is `v_pk_fma_f32 D, A, A, C op_sel:[0,0,1] op_sel_hi:[1,1,0]` (lo result = A.lo^2 + C.HI).
+                            // On this MI355X a packed fp32 op whose LO result takes the HI half of src1 / src2 reads that half
+                            // as ZERO in lanes 48-63 whenever the SIMD's matrix pipe is busy (this kernel's neighbours are in
+                            // their K loops): one term of one quarter-wave lost, in 4-28 % of the launches of the 64 x 64 tile.
+                            // Stand-alone proof: tools/abl/pk_fma_opsel_repro.hip; in this kernel: tools/abl/probe_5d.py.  The
+                            // empty asm makes sq opaque between additions, so no vector chain can be formed from it, and
+                            // tools/check_isa.py (rule 4) rejects any such instruction anywhere in the shipped code object.
+#if !(defined(CODAE_DBG_5D) && (CODAE_DBG_5D & 1))
                             asm volatile("" : "+v"(sq));
+#endif
                             const uint32_t mb = ((k < 4 ? m.x : m.y) >> (8 * (k & 3))) & 0xff;
                             if (mb == 0) sqp += se;
                             gq[k] = -2.f * d * L.inv_n;
@@ -380,6 +426,12 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmBf16& g, int tiles_n, i
             }
             __syncthreads();
         }
+#if defined(CODAE_DBG_5D) && (CODAE_DBG_5D & 4)
+        sq = sq2[0] + sq2[1];
+#endif
+#if defined(CODAE_DBG_5D) && (CODAE_DBG_5D & 2)
+        if (bid < DBG5D_WGS && NT == 256) { g_dbg5d[(bid * 256 + threadIdx.x) * 2] = sq; g_dbg5d[(bid * 256 + threadIdx.x) * 2 + 1] = sqp; }
+#endif
         // block sums -> scalars; column sums -> bias gradient
         float* red = reinterpret_cast<float*>(smem_raw);
         static_assert(RL * BN * 4 + 64 <= 2 * BUF_BYTES, "reduction scratch must fit");
@@ -720,4 +772,12 @@ int gemm_bf16(const GemmBf16& g, hipStream_t s) {
     }
 }
 
+#if defined(CODAE_DBG_5D) && (CODAE_DBG_5D & 2)
+}  // namespace codae
+extern "C" int codae_debug_5d(float* host_out, int n_floats) {
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(codae::g_dbg5d), (size_t)n_floats * sizeof(float)) != hipSuccess) return -1;
+    return 0;
+}
+namespace codae {
+#endif
 }  // namespace codae

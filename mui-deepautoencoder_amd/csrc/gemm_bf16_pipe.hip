@@ -387,7 +387,7 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
                                 const float d = on ? xs[k] - yv[k] : 0.f;
                                 const float se = d * d;
                                 sq += se;
-                                asm volatile("" : "+v"(sq));     // scalar chain: see the fused-loss epilogue of gemm_bf16.hip
+                                asm volatile("" : "+v"(sq));     // scalar chain, never packed with op_sel half swaps: gemm_bf16.hip, DESIGN.md 5d
                                 sqp += ((mk[mt][nh][nt] >> (8 * k)) & 0xffu) == 0 ? se : 0.f;
                                 gq[k] = on ? -2.f * d * L.inv_n : 0.f;       // (+0 in pad rows / columns)
                                 cs[nh][nt][k] += gq[k];

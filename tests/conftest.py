@@ -22,7 +22,21 @@ def _has_gpu():
         return False
 
 
+# Collection order on the GPU box (the driver runs `pytest tests -x -q -m gpu`): kernel tests, then the parity
+# replays, then everything that starts subprocesses or needs wall-clock to make sense.  With -x the first failure hides
+# every later test, so nothing end-to-end may come before the parity tests (round 2: a bench-line test that sorted
+# first alphabetically failed on a cold box and hid 213 others).
+_ORDER = ["test_oracle_golden", "test_host_logic", "test_dp_gloo", "test_gpu_kernels", "test_gpu_parity",
+          "test_gpu_abalone", "test_gpu_scripts", "test_gpu_dp_ranks", "test_gpu_bench"]
+
+
+def _rank(item):
+    name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+    return _ORDER.index(name) if name in _ORDER else len(_ORDER) - 3       # unknown files: before the subprocess tests
+
+
 def pytest_collection_modifyitems(config, items):
+    items.sort(key=_rank)          # (stable: the order inside a file is kept)
     if _has_gpu():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")
