@@ -46,7 +46,8 @@ def test_default_bench_line_c3_with_fp32_parity_leg():
     assert by[r["kernel"]]["sampled_steps"] >= 3, line
     rs = d["roofline_step"]
     assert rs["bound"] == "mfma" and abs(rs["frac"] - rs["achieved"] / rs["peak"]) < 1e-9 and 0.0 < rs["frac"] < 1.0, line
-    assert d["f32_parity"]["ms_per_step"] > d["ms_per_step"], line
+    f = d["f32_parity"]
+    assert f["ms_per_step"] > 0 and f["steps"] == 10 and abs(f["samples_per_s"] - 8192 / (f["ms_per_step"] * 1e-3)) <= 1e-6 * f["samples_per_s"], line
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1, line
 
