@@ -39,9 +39,11 @@ extern "C" {
  *   3: codae_buffers.bias_parts, codae_sizes.bias_part_bytes, CODAE_K_CHAIN / CODAE_K_BIAS_FINISH, codae_span_sumsq,
  *      codae_step_update_span, codae_sync_transposed, codae_dgrad_bf16's partial-sum workspace
  *   4: + codae_ranking_loss_batched, codae_gather_inventory_rows, codae_step_path (new entries only; no layout change)
+ *   5: + codae_monitor_accumulate; codae_ranking_loss_batched takes val_group (rows of the validation inventory that are
+ *      exact duplicates of each other) behind val_pos
  * The binding must refuse a library whose codae_abi_version() differs and must check its own struct sizes against
  * codae_struct_sizes() at load (mui-deepautoencoder_amd/codae/hip/__init__.py does both). */
-#define CODAE_ABI_VERSION 4
+#define CODAE_ABI_VERSION 5
 
 enum {
     CODAE_OK = 0,
@@ -295,6 +297,20 @@ int codae_combined_loss_fwd_bwd(const float* x, const float* y, int32_t B, int32
 /* CombinedCriterion(reduction="none") (metering.py:131-152): out[B][n_var] = squared error (size-1 regression) or NLL */
 int codae_combined_loss_full(const float* x, const float* y, int32_t B, int32_t io, int32_t n_var, const int32_t* var_pos,
                              const int32_t* var_size, const int32_t* var_type, float* out, void* stream);
+/* The abalone script's per-step accounting (script/train_dae_on_abalone.py:227-236 of the reference; metering.py:131-152,
+ * 187-204) without leaving the device: the monitor criterion L[b][v] of (x', y') - squared error of a size-1 regression
+ * variable, NLL of a one-hot block - where x' = x * undo_scale + undo_min per column (Normalizer.undo, data_tool.py:80-90;
+ * both NULL = identity; a one-hot column has scale 1, min 0), added into
+ *   acc[0]                       f   += sum_{b,v} L[b][v]
+ *   acc[1]                       p   += sum_{b,v} L[b][v] [variable v is blanked in sample b]        (get_partial)
+ *   acc[2 + k*n_var + v]         f_k += sum_{b: k_b = k+1} L[b][v]                                    (get_per_k)
+ *   acc[2 + (k_max+k)*n_var + v] p_k += sum_{b: k_b = k+1} L[b][v] [v blanked in b]
+ * with k_b = k_of_mask[mask_id[b]] and "blanked" = mask_table[mask_id[b]][var_pos[v]] == 0 (the Corrupter's tables).  fp64
+ * accumulators, one workgroup, additions in a fixed order (the same bits every run); read them once per epoch.  k_max <= 16. */
+int codae_monitor_accumulate(const float* x, const float* y, int32_t B, int32_t io, int32_t n_var, const int32_t* var_pos,
+                             const int32_t* var_size, const int32_t* var_type, const float* undo_scale, const float* undo_min,
+                             const int32_t* mask_id, const uint8_t* mask_table, const int32_t* k_of_mask, int32_t k_max,
+                             double* acc, void* stream);
 /* out[r] = ||m[r][:]||_2 */
 int codae_row_norms(const float* m, int64_t rows, int32_t E, float* out, void* stream);
 /* RankingLoss.get (metering.py:46-79): *out += sum_b 1 - rank_b / (n_val - 1); inventory [n_slots][n_obs][E] =
@@ -310,14 +326,19 @@ int codae_ranking_loss(const float* pred, const float* fmask, const int32_t* idx
  * validation rows at a time; *out += sum_b 1 - rank_b / (n_val - 1) (accumulates over the batches of an epoch).
  * inv_val [n_slots][n_val][E] = codae_gather_inventory_rows(inventory, val_idx), inv_val_norm its row norms;
  * val_pos [n_obs]: position of an observation in val_idx or -1 (a sample's own validation row is never counted: the
- * reference compares s[idx] with itself there), may be NULL.  Every slot's GEMM runs over the rows that blank THAT slot
+ * reference compares s[idx] with itself there), may be NULL.  val_group [n_slots][n_val] (or NULL): rows of one slot's
+ * validation inventory with the same group id hold the same bytes; the reference never counts such a row against the
+ * sample it duplicates either (its two similarities come out of ONE cosine_similarity call and s[idx] > s[j] is false for
+ * equal values), while here the sample's own similarity and the GEMM's column are summed in different orders - so exact
+ * duplicates are skipped by identity, not by arithmetic coincidence.  Every slot's GEMM runs over the rows that blank THAT slot
  * only (compacted on the device).  Workspaces: work B * chunk floats; row_state 32 * B bytes; perm_ws (n_slots * B +
  * n_slots) int32; q_ws B * E floats. */
 int codae_ranking_loss_batched(const float* pred, int32_t B, int32_t io, int32_t n_slots, int32_t E, const int32_t* row_idx,
                                const int32_t* mask_id, const int32_t* mask_to_use, int32_t nb_run, int32_t run,
                                const uint8_t* mask_table, const float* inventory, const float* inventory_norm, int64_t n_obs,
-                               const float* inv_val, const float* inv_val_norm, const int32_t* val_pos, int32_t n_val, float* work,
-                               int32_t chunk, void* row_state, int32_t* perm_ws, float* q_ws, double* out, void* stream);
+                               const float* inv_val, const float* inv_val_norm, const int32_t* val_pos, const int32_t* val_group,
+                               int32_t n_val, float* work, int32_t chunk, void* row_state, int32_t* perm_ws, float* q_ws, double* out,
+                               void* stream);
 /* dst[c][j][:] = inventory[c][val_idx[j]][:]  (inventory [n_slots][n_obs][E]) */
 int codae_gather_inventory_rows(const float* inventory, int64_t n_obs, int32_t E, int32_t n_slots, const int32_t* val_idx,
                                 int32_t n_val, float* dst, void* stream);

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("CODAE_HIP_LIB") or os.path.join(_HERE, "libcodae_hip.
 PREC_F32 = 0
 PREC_BF16 = 1
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 # CODAE_S_* of include/codae_hip.h (tests/test_host_logic.py parses the header and compares)
 S_SQ_FULL, S_SQ_PARTIAL, S_GRAD_SQ, S_LAST_LOSS, S_STEP_SQ, S_CLIP_COEF = 0, 1, 2, 3, 4, 5
 S_GRAD_SQ_SLOTS, S_N_SLOTS, S_ADAM_STEP, S_COUNT = 8, 64, 72, 80
@@ -98,8 +98,9 @@ PROTOTYPES = {
     "codae_combined_loss_full": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
     "codae_row_norms": (C.c_int, [_P, _I64, _I32, _P, _P]),
     "codae_ranking_loss": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _I64, _P, _I32, _P, _P]),
-    "codae_ranking_loss_batched": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _I32, _I32, _P, _P, _P, _I64, _P, _P, _P, _I32, _P,
+    "codae_ranking_loss_batched": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _I32, _I32, _P, _P, _P, _I64, _P, _P, _P, _P, _I32, _P,
                                              _I32, _P, _P, _P, _P, _P]),
+    "codae_monitor_accumulate": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P]),
     "codae_gather_inventory_rows": (C.c_int, [_P, _I64, _I32, _I32, _P, _I32, _P, _P]),
     "codae_step_path": (C.c_int, [_P, _P, _I32]),
     "codae_linear_f32": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),

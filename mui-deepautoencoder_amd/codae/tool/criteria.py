@@ -87,6 +87,11 @@ class RankingLoss:
             pos = torch.full((self._inv.shape[1],), -1, dtype=torch.int32)
             pos[torch.as_tensor(list(self.validation_indices), dtype=torch.long)] = torch.arange(V, dtype=torch.int32)
             self._val_pos = pos.to(dev)
+            # rows of a slot's validation inventory that hold the same bytes share a group id: the reference never counts an exact
+            # copy of the sample's own row (equal similarities out of one cosine_similarity call), so neither may we (codae_hip.h)
+            groups = [torch.unique(self._inv_val[c], dim=0, return_inverse=True)[1] for c in range(S)]
+            grp = torch.stack(groups).to(torch.int32).contiguous()
+            self._val_group = grp if int(grp.max()) + 1 < V else None          # (no duplicates: nothing to skip)
             self._acc = torch.zeros(1, dtype=torch.float64, device=dev)
             self._work = None
 
@@ -113,8 +118,9 @@ class RankingLoss:
             _check(_hip_lib().codae_ranking_loss_batched(
                 _ptr(pred), B, pred.shape[1], S, E, _ptr(row_idx), None, _ptr(m2u), m2u.shape[1], int(run),
                 _ptr(corrupter.mask_table_u8), _ptr(self._inv), _ptr(self._inv_norm), self._inv.shape[1],
-                _ptr(self._inv_val), _ptr(self._inv_val_norm), _ptr(self._val_pos), V, _ptr(self._work), chunk, _ptr(self._rows), _ptr(self._perm), _ptr(self._q), _ptr(self._acc),
-                _stream()))
+                _ptr(self._inv_val), _ptr(self._inv_val_norm), _ptr(self._val_pos),
+                _ptr(self._val_group) if self._val_group is not None else None, V, _ptr(self._work), chunk, _ptr(self._rows),
+                _ptr(self._perm), _ptr(self._q), _ptr(self._acc), _stream()))
         self._keep = (pred, row_idx)             # (alive until the stream has consumed them)
 
     def total(self, reset=True):
@@ -215,6 +221,46 @@ class CombinedCriterion:
             _check(_hip_lib().codae_combined_loss_full(_ptr(x), _ptr(y), y.shape[0], y.shape[1], len(self.arch), _ptr(pos),
                                                        _ptr(size), _ptr(typ), _ptr(out), _stream()))
         return out
+
+    # ---- device-resident per-step accounting of the abalone sweep -----------------------------------
+    def accumulate(self, x, y, mask_ids, corrupter, normalizer=None, first_scaled_column=0):
+        """What script/train_dae_on_abalone.py:227-236 of the reference does on the host after every step - the monitor
+        criterion of the de-normalised batch, `get_partial`, two `get_per_k`s and four running sums - as ONE launch that
+        adds into fp64 tables on the device (codae_monitor_accumulate).  `mask_ids`: int32 device tensor = the Corrupter's
+        mask-table row per sample (`corrupter.mask_ids(batch_indices, run)`); `normalizer`: a tool.Normalizer whose `undo` the
+        script applies to columns >= first_scaled_column of x and y (None: none).  Nothing is copied to the host; read the
+        epoch's tables with `accumulated()`."""
+        dev = y.device
+        pos, size, typ, _, _ = self._tables(dev)
+        nv, k_max = len(self.arch), self.k_max
+        if getattr(self, "_mon_acc", None) is None or self._mon_acc.device != dev:
+            self._mon_acc = torch.zeros(2 + 2 * k_max * nv, dtype=torch.float64, device=dev)
+            self._mon_undo = None
+        if normalizer is not None and self._mon_undo is None:
+            io = x.shape[1]
+            sc = torch.ones(io, dtype=torch.float32, device=dev)
+            mn = torch.zeros(io, dtype=torch.float32, device=dev)
+            sc[first_scaled_column:] = normalizer.scale.to(dev, torch.float32)
+            mn[first_scaled_column:] = normalizer.min.to(dev, torch.float32)
+            self._mon_undo = (sc.contiguous(), mn.contiguous())
+        x = x.detach().to(torch.float32).contiguous()
+        y = y.detach().to(torch.float32).contiguous()
+        us, um = self._mon_undo if normalizer is not None else (None, None)
+        with torch.cuda.device(dev):
+            _check(_hip_lib().codae_monitor_accumulate(_ptr(x), _ptr(y), y.shape[0], y.shape[1], nv, _ptr(pos), _ptr(size), _ptr(typ),
+                                                       _ptr(us) if us is not None else None, _ptr(um) if um is not None else None,
+                                                       _ptr(mask_ids), _ptr(corrupter.mask_table_u8), _ptr(corrupter.k_of_mask_i32),
+                                                       k_max, _ptr(self._mon_acc), _stream()))
+        self._mon_keep = (x, y, mask_ids)          # (alive until the stream has consumed them)
+
+    def accumulated(self, reset=True):
+        """(f, p, f_k [k_max, n_var], p_k [k_max, n_var]) summed over the accumulate() calls since the last reset: float64
+        numpy, one device-to-host copy."""
+        nv, k_max = len(self.arch), self.k_max
+        a = self._mon_acc.cpu().numpy().copy()
+        if reset:
+            self._mon_acc.zero_()
+        return float(a[0]), float(a[1]), a[2:2 + k_max * nv].reshape(k_max, nv), a[2 + k_max * nv:].reshape(k_max, nv)
 
     def _per_variable(self, x, y, v):
         p, s = v["position"], v["size"]

@@ -91,7 +91,8 @@ struct EnvToggles {
     int group_tile = -1;         // CODAE_GROUP_TILE: grouped weight gradients on 128 x 128 (0), 64 x 128 (1), 64 x 64 (2); -1 = automatic
     bool side_priority_set = false; int side_priority = 0;   // CODAE_SIDE_PRIORITY
     bool no_wt = false, single_stream = false, tail_on_side = false, no_fused_loss = false, flat_adam = false,
-         no_fused_norm = false, no_chain = false, no_deep_small = false;      // CODAE_NO_DEEP_SMALL: 2-stage small GEMMs
+         no_fused_norm = false, no_chain = false, no_deep_small = false,      // CODAE_NO_DEEP_SMALL: 2-stage small GEMMs
+         no_defer_wgrad = false;      // CODAE_NO_DEFER_WGRAD: per-layer split-K weight gradients beside the data-gradient chain (round 2's backward)
 };
 const EnvToggles& env();
 void env_reload();
@@ -170,6 +171,7 @@ struct GemmBf16Group {
     int wg_begin[CODAE_GROUP_MAX + 1];     // prefix sum of workgroups per GEMM (filled by the launcher)
 };
 int gemm_bf16_grouped(GemmBf16Group& grp, hipStream_t s);
+int gemm_bf16_pipe_grouped(GemmBf16Group& grp, hipStream_t s);   // 256 x 192 pipelined tiles, unsplit K (gemm_bf16_pipe.hip)
 
 // ---- persistent fused chain for narrow stacks (chain_bf16.hip) ----------------
 constexpr int CODAE_CHAIN_MAX_WIDTH = 512;

@@ -108,6 +108,61 @@ __global__ __launch_bounds__(NT) void combined_full_kernel(const float* __restri
     }
 }
 
+// Per-step accounting of the abalone sweep (train_dae_on_abalone.py:227-236): ONE workgroup; thread (r, v) walks rows r, r + R,
+// ... of variable v and keeps {f_k, p_k}[k] for its variable in LDS (its own slots: no atomics); thread v then adds the R
+// partials of its variable in row-lane order and folds them into the fp64 tables - every addition in a fixed order.
+constexpr int MON_KMAX = 16;
+__global__ __launch_bounds__(NT) void monitor_accumulate_kernel(const float* __restrict__ x, const float* __restrict__ y, int B, int io, int nv,
+                                                                const int32_t* __restrict__ pos, const int32_t* __restrict__ size,
+                                                                const int32_t* __restrict__ type, const float* __restrict__ us,
+                                                                const float* __restrict__ um, const int32_t* __restrict__ mask_id,
+                                                                const uint8_t* __restrict__ table, const int32_t* __restrict__ k_of_mask,
+                                                                int k_max, double* __restrict__ acc) {
+    extern __shared__ double part[];                     // [NT][2 * k_max]
+    const int R = NT / nv;                               // row lanes (host checks nv <= NT)
+    const int r = threadIdx.x / nv, v = threadIdx.x - r * nv;
+    double* mine = part + (size_t)threadIdx.x * 2 * k_max;
+    for (int k = 0; k < 2 * k_max; ++k) mine[k] = 0.0;
+    if (r < R) {
+        const int p = pos[v], s = size[v], t = type[v];
+        for (int b = r; b < B; b += R) {
+            const float* xr = x + (int64_t)b * io;
+            const float* yr = y + (int64_t)b * io;
+            float val;
+            if (t == 0) {
+                const float sc = us ? us[p] : 1.f, mn = um ? um[p] : 0.f;
+                const float xu = xr[p] * sc + mn, yu = yr[p] * sc + mn;      // (data * scale) + min, fp32, as torch
+                const float d = xu - yu;
+                val = d * d;
+            } else {
+                val = -log_softmax_at(yr, p, s, argmax_first(xr, p, s));     // (one-hot columns are not de-normalised)
+            }
+            const int id = mask_id[b];
+            const int k = k_of_mask[id] - 1;
+            if (k >= 0 && k < k_max) {
+                mine[k] += (double)val;
+                if (table[(int64_t)id * io + p] == 0) mine[k_max + k] += (double)val;
+            }
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nv) {
+        for (int k = 0; k < 2 * k_max; ++k) {
+            double t = 0.0;
+            for (int rr = 0; rr < R; ++rr) t += part[(size_t)(rr * nv + threadIdx.x) * 2 * k_max + k];
+            acc[2 + (int64_t)k * nv + threadIdx.x] += t;
+            part[(size_t)threadIdx.x * 2 * k_max + k] = t;       // (slot of row lane 0: read back by thread 0 below)
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double f = 0.0, pp = 0.0;
+        for (int k = 0; k < k_max; ++k)
+            for (int vv = 0; vv < nv; ++vv) { f += part[(size_t)vv * 2 * k_max + k]; pp += part[(size_t)vv * 2 * k_max + k_max + k]; }
+        acc[0] += f; acc[1] += pp;
+    }
+}
+
 // ||row||_2 of a [rows][E] matrix, one wave per row
 __global__ __launch_bounds__(NT) void row_norm_kernel(const float* __restrict__ m, int64_t rows, int E, float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -178,15 +233,16 @@ __global__ __launch_bounds__(NT) void ranking_kernel(const float* __restrict__ p
 // followed by a compare-count pass; the batch's mask ids come from the Corrupter's device tables, nothing goes
 // through the host, and *out accumulates over the batches of an epoch.
 //   rs[b] = {slot c, |q| clamped, own similarity, rank so far}
-struct RankRow { int slot; float qn; float own; int rank; int self_col; int pad[3]; };
+struct RankRow { int slot; float qn; float own; int rank; int self_col; int pad[3]; };      // pad[1]: duplicate group of the own row or -1
 
 // one wave per sample: blanked slot from the mask table (metering.py:56: sum of the blanked slots' indices), |q|, s[idx_b]
 __global__ __launch_bounds__(NT) void rank_prep_kernel(const float* __restrict__ pred, const int32_t* __restrict__ row_idx,
                                                        const int32_t* __restrict__ mask_id, const int32_t* __restrict__ mask_to_use,
                                                        int nb_run, int run, const uint8_t* __restrict__ mask_table, int B, int io, int S,
                                                        int E, const float* __restrict__ inv, const float* __restrict__ inv_norm,
-                                                       int64_t n_obs, const int32_t* __restrict__ val_pos, RankRow* __restrict__ rs,
-                                                       int32_t* __restrict__ perm, int32_t* __restrict__ counts) {
+                                                       int64_t n_obs, const int32_t* __restrict__ val_pos, const int32_t* __restrict__ val_group,
+                                                       int n_val, RankRow* __restrict__ rs, int32_t* __restrict__ perm,
+                                                       int32_t* __restrict__ counts) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -210,15 +266,17 @@ __global__ __launch_bounds__(NT) void rank_prep_kernel(const float* __restrict__
         // the rows of one slot, compacted (in arrival order: which GEMM row a sample lands on does not change its rank)
         const int k = atomicAdd(&counts[c], 1);
         perm[(int64_t)c * B + k] = b;
-        o.pad[0] = k; o.pad[1] = o.pad[2] = 0;
+        // rows of the inventory that are exact copies of the sample's own row are never counted either (see codae_hip.h)
+        o.pad[0] = k; o.pad[1] = (val_group && o.self_col >= 0) ? val_group[(int64_t)c * n_val + o.self_col] : -1; o.pad[2] = 0;
         rs[b] = o;
     }
 }
 
 // compact rows of slot c (k < counts[c]; sample perm[c][k]): rank += #{ j < n : own > dots[k][j] / (|q| |inv_j|) }; one wave per row
 __global__ __launch_bounds__(NT) void rank_count_kernel(const float* __restrict__ dots, int64_t ld, int B, int n, int c, int v0,
-                                                        const float* __restrict__ val_norm, RankRow* __restrict__ rs,
-                                                        const int32_t* __restrict__ perm, const int32_t* __restrict__ counts) {
+                                                        const float* __restrict__ val_norm, const int32_t* __restrict__ group,
+                                                        RankRow* __restrict__ rs, const int32_t* __restrict__ perm,
+                                                        const int32_t* __restrict__ counts) {
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
     if (k >= counts[c]) return;
@@ -227,7 +285,11 @@ __global__ __launch_bounds__(NT) void rank_count_kernel(const float* __restrict_
     const float* d = dots + (int64_t)k * ld;
     int cnt = 0;
     const int skip = me.self_col - v0;
-    for (int j = lane; j < n; j += 64) cnt += (j != skip && me.own > d[j] / (me.qn * fmaxf(val_norm[j], 1e-8f))) ? 1 : 0;
+    const int grp = me.pad[1];          // (group: this chunk's slice of the slot's duplicate-group ids, or null)
+    for (int j = lane; j < n; j += 64) {
+        const bool same = (j == skip) || (group != nullptr && grp >= 0 && group[j] == grp);
+        cnt += (!same && me.own > d[j] / (me.qn * fmaxf(val_norm[j], 1e-8f))) ? 1 : 0;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
     if (lane == 0) rs[b].rank = me.rank + cnt;
@@ -310,6 +372,20 @@ int codae_combined_loss_full(const float* x, const float* y, int32_t B, int32_t 
     return CODAE_OK;
 }
 
+int codae_monitor_accumulate(const float* x, const float* y, int32_t B, int32_t io, int32_t n_var, const int32_t* var_pos,
+                             const int32_t* var_size, const int32_t* var_type, const float* undo_scale, const float* undo_min,
+                             const int32_t* mask_id, const uint8_t* mask_table, const int32_t* k_of_mask, int32_t k_max,
+                             double* acc, void* stream) {
+    CODAE_REQUIRE(x && y && var_pos && var_size && var_type && mask_id && mask_table && k_of_mask && acc, "monitor_accumulate: null argument");
+    CODAE_REQUIRE(B > 0 && io > 0 && n_var > 0 && n_var <= NT, "monitor_accumulate: bad sizes (B %d, io %d, n_var %d)", B, io, n_var);
+    CODAE_REQUIRE(k_max >= 1 && k_max <= MON_KMAX, "monitor_accumulate: k_max %d outside [1, %d]", k_max, MON_KMAX);
+    CODAE_REQUIRE((undo_scale == nullptr) == (undo_min == nullptr), "monitor_accumulate: undo_scale and undo_min come together");
+    hipLaunchKernelGGL(monitor_accumulate_kernel, dim3(1), dim3(NT), (size_t)NT * 2 * k_max * sizeof(double), (hipStream_t)stream, x, y, B,
+                       io, n_var, var_pos, var_size, var_type, undo_scale, undo_min, mask_id, mask_table, k_of_mask, k_max, acc);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
 int codae_row_norms(const float* m, int64_t rows, int32_t E, float* out, void* stream) {
     CODAE_REQUIRE(m && out && rows > 0 && E > 0, "row_norms: bad argument");
     int64_t g = (rows + 3) / 4;
@@ -343,8 +419,9 @@ int codae_gather_inventory_rows(const float* inventory, int64_t n_obs, int32_t E
 int codae_ranking_loss_batched(const float* pred, int32_t B, int32_t io, int32_t n_slots, int32_t E, const int32_t* row_idx,
                                const int32_t* mask_id, const int32_t* mask_to_use, int32_t nb_run, int32_t run,
                                const uint8_t* mask_table, const float* inventory, const float* inventory_norm, int64_t n_obs,
-                               const float* inv_val, const float* inv_val_norm, const int32_t* val_pos, int32_t n_val, float* work,
-                               int32_t chunk, void* row_state, int32_t* perm_ws, float* q_ws, double* out, void* stream) {
+                               const float* inv_val, const float* inv_val_norm, const int32_t* val_pos, const int32_t* val_group,
+                               int32_t n_val, float* work, int32_t chunk, void* row_state, int32_t* perm_ws, float* q_ws, double* out,
+                               void* stream) {
     CODAE_REQUIRE(pred && row_idx && (mask_id || mask_to_use) && mask_table && inventory && inventory_norm && inv_val && inv_val_norm &&
                       work && row_state && perm_ws && q_ws && out, "ranking_loss_batched: null argument");
     CODAE_REQUIRE(B > 0 && n_slots > 0 && E > 0 && io == n_slots * E && n_val > 1 && n_obs > 0 && chunk > 0, "ranking_loss_batched: bad sizes");
@@ -356,7 +433,7 @@ int codae_ranking_loss_batched(const float* pred, int32_t B, int32_t io, int32_t
     CODAE_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)n_slots * sizeof(int32_t), s));
     const int rows_grid = (B + NT / 64 - 1) / (NT / 64);
     hipLaunchKernelGGL(rank_prep_kernel, dim3(rows_grid), dim3(NT), 0, s, pred, row_idx, mask_id, mask_to_use, nb_run, run, mask_table, B,
-                       io, n_slots, E, inventory, inventory_norm, n_obs, val_pos, rs, perm, counts);
+                       io, n_slots, E, inventory, inventory_norm, n_obs, val_pos, val_group, n_val, rs, perm, counts);
     CODAE_LAUNCH_CHECK();
     // per slot: its rows' queries gathered, then one GEMM per chunk of validation rows over THOSE rows only (the row count
     // stays on the device: the grid covers B rows, tiles past counts[c] return at once), then the compare-count pass
@@ -374,7 +451,8 @@ int codae_ranking_loss_batched(const float* pred, int32_t B, int32_t io, int32_t
             int rc = gemm_f32(g, s);
             if (rc) return rc;
             hipLaunchKernelGGL(rank_count_kernel, dim3(rows_grid), dim3(NT), 0, s, work, (int64_t)chunk, B, n, c, v0,
-                               inv_val_norm + (int64_t)c * n_val + v0, rs, perm, counts);
+                               inv_val_norm + (int64_t)c * n_val + v0, val_group ? val_group + (int64_t)c * n_val + v0 : nullptr, rs, perm,
+                               counts);
             CODAE_LAUNCH_CHECK();
         }
     }

@@ -40,6 +40,7 @@ void env_reload() {
     e.no_fused_norm = getenv("CODAE_NO_FUSED_NORM") != nullptr;
     e.no_chain = getenv("CODAE_NO_CHAIN") != nullptr;
     e.no_deep_small = getenv("CODAE_NO_DEEP_SMALL") != nullptr;
+    e.no_defer_wgrad = getenv("CODAE_NO_DEFER_WGRAD") != nullptr;
     if (const char* k = getenv("CODAE_SMALL_TILE_MAX")) e.small_tile_max = atoi(k);
     if (const char* k = getenv("CODAE_SMALL_STAGES")) e.small_stages = atoi(k) == 2 ? 2 : 4;
     g_env = e;
@@ -128,6 +129,8 @@ struct ProfScope {
             (void)hipEventRecord(e->prof_start[slot], s);
         }
     }
+    // the launches made inside count as `n` of this class (a grouped launch: one record, reported as n launches of elapsed / n)
+    void counts_as(int n) { if (slot >= 0) e->prof_count[slot] = n; }
     ~ProfScope() {
         if (slot >= 0) (void)hipEventRecord(e->prof_stop[slot], s);
     }
@@ -318,6 +321,40 @@ int run_wgrad_grouped(const codae_engine* e, const codae_buffers* b, int rows, b
         if (rc) return rc;
     }
     return CODAE_OK;
+}
+
+// Wide bf16 stack, single-GPU fused step: every layer's weight gradient in ONE launch of 256 x 192 tiles with K = the whole batch
+// (no split-K slabs, no reduce pass; sum g^2 from the epilogue), issued AFTER the data-gradient chain, which then has the chip to
+// itself.  Needs dA_l of every layer alive at once (n_dact > L).  Worth it when no single layer's weight gradient can fill the
+// chip unsplit (C3: 48 tiles per layer -> round 2 split K five ways: 47 MB of fp32 slabs written and read back per layer,
+// 0.28 ms of reduce launches per step) but all of them together can (480 tiles on 256 CUs).
+bool defer_wgrad_ok(const codae_engine* e, int rows) {
+    if (e->prec != CODAE_PREC_BF16 || e->cfg.no_defer_wgrad || e->cfg.single_stream || e->L > CODAE_GROUP_MAX || e->n_dact <= e->L || rows < 1024)
+        return false;
+    int total = 0, largest = 0;
+    for (int l = 0; l < e->L; ++l) {
+        const int t = ((e->out[l] + 255) / 256) * ((e->in[l] + 191) / 192);
+        total += t;
+        if (t > largest) largest = t;
+        if ((int64_t)rows * e->out[l] * 2 >= (int64_t)1 << 32 || (int64_t)rows * e->in[l] * 2 >= (int64_t)1 << 32) return false;
+    }
+    return largest < 160 && total >= 200;
+}
+
+int run_wgrad_deferred(const codae_engine* e, const codae_buffers* b, int rows, hipStream_t s) {
+    GemmBf16Group grp{};
+    grp.n = 0;
+    for (int l = e->L - 1; l >= 0; --l) {            // (backward order: the layers whose operands were touched last come first)
+        GemmBf16& g = grp.g[grp.n++];
+        g.A = reinterpret_cast<const bf16_t*>(dact_ptr(e, b, l)); g.lda = e->out[l]; g.a_mode = OP_KS;
+        g.B = reinterpret_cast<const bf16_t*>(act_ptr(e, b, l)); g.ldb = e->in[l]; g.b_mode = OP_KS;
+        g.C = b->grads + e->w_off[l]; g.ldc = e->in[l]; g.c_f32 = 1;
+        g.M = e->out[l]; g.N = e->in[l]; g.K = rows; g.split_k = 1;
+        g.sumsq_slots = e->norm_in_backward ? b->scalars + CODAE_S_GRAD_SQ_SLOTS : nullptr;
+    }
+    ProfScope prof(e, CODAE_K_GEMM_WGRAD, s);
+    prof.counts_as(grp.n);
+    return gemm_bf16_pipe_grouped(grp, s);
 }
 
 // Exact-fp32 GEMM of a launch too small to fill the chip (forward / data gradient of a small batch): K split over
@@ -533,6 +570,18 @@ int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi
     // (Measured and dropped: the slab reduces on the caller's stream one layer late, or on a third stream - no
     // gain, 1.83 / 1.84 vs 1.82 ms at the time; every GEMM on the caller's stream with only the reduces beside
     // them - 0.27 ms slower: each cross-queue event costs ~10 us.)
+    if (step_mode && join && lo == 0 && hi == h->L && h->L >= 2 && defer_wgrad_ok(h, rows)) {
+        // data-gradient chain alone on the chip, then all weight gradients in one launch (see defer_wgrad_ok); one stream
+        int rc = join_side(h, s);                  // (an earlier bucketed backward may have left work on the side stream)
+        if (rc) return rc;
+        for (int l = hi - 1; l >= 1; --l) {
+            rc = run_dgrad(h, b, l, rows, nullptr, s);
+            if (rc) return rc;
+        }
+        rc = run_wgrad_deferred(h, b, rows, s);
+        if (rc) return rc;
+        return finish_bias(h, b, s, h->norm_in_backward);
+    }
     bool* w_pending = h->w_pending;
     for (int l = hi - 1; l >= lo; --l) {
         int rc;

@@ -51,9 +51,12 @@ __device__ unsigned long long g_timeline[TIMELINE_WGS * TIMELINE_SLOTS];
 // activation + column sums = bias gradient), 3 = last forward layer of a training step with the MSE loss, its gradient
 // and the metric sums computed straight from the accumulators (g.loss), 0 = everything decided at run time.  Apart from trimming the forward's
 // epilogue this gives the forward and the data-gradient launches distinct kernel symbols in rocprofv3 traces.
+// One output tile (or split-K range of one) of one GEMM: the whole kernel body, shared by the plain kernel (one GEMM per
+// launch) and the grouped kernel (the weight gradients of every layer in one launch).  wg / nwg: this workgroup's index
+// among the nwg workgroups of ITS GEMM; smem_raw: 2 * BUF (+ BM * 8 for EPI 3) bytes of LDS.
 template <int BM, int BN, int WM, int WN, int NLB, int A_MODE, int B_MODE, bool C_F32, int DBG = 0, int EPI = 0>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4)
-void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
+__device__ __forceinline__ void gemm_bf16_pipe_tile(const GemmBf16& g, int tiles_n, int tiles_mn, int kt_total, int wg, int nwg,
+                                                    char* smem_raw) {
     constexpr int NW = WM * WN;
     constexpr int SM = BM / WM, SN = BN / WN;        // wave sub-tile
     constexpr int AHR = BM / 2, BHR = BN / 2;        // rows / cols per half-tile
@@ -70,17 +73,13 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
     constexpr int NA = AHR / 8 / NLA, NB = BHR / 8 / NLB;
     static_assert(NLB <= NW && NLA <= NW && (AHR / 8) % NLA == 0 && (BHR / 8) % NLB == 0, "loader waves");
     static_assert(SM % 32 == 0 && SN % 32 == 0, "wave sub-tile must split into 16-wide half tiles");
-    // (EPI = 3: + {dataset row, mask id} of the tile's rows; ONE array: a second __shared__ object beside an LDS-DMA
-    // staging array makes the compiler drain vmcnt in front of LDS reads)
-    __shared__ __attribute__((aligned(16))) char smem_raw[2 * BUF + (EPI == 3 ? BM * 8 : 0)];
     lds_char* smem = (lds_char*)smem_raw;
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = w / WN, wc = w % WN;
 
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
+    int bid = wg;
     {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -621,10 +620,35 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
             if (threadIdx.x == 0) {
                 float t = 0.f;
                 for (int ww = 0; ww < NW; ++ww) t += red[ww];
-                atomicAdd(g.sumsq_slots + (blockIdx.x & (CODAE_S_N_SLOTS - 1)), (double)t);
+                atomicAdd(g.sumsq_slots + (wg & (CODAE_S_N_SLOTS - 1)), (double)t);
             }
         }
     }
+}
+
+template <int BM, int BN, int WM, int WN, int NLB, int A_MODE, int B_MODE, bool C_F32, int DBG = 0, int EPI = 0>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4)
+void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) {
+    // (EPI = 3: + {dataset row, mask id} of the tile's rows; ONE array: a second __shared__ object beside an LDS-DMA
+    // staging array makes the compiler drain vmcnt in front of LDS reads)
+    __shared__ __attribute__((aligned(16))) char smem_raw[2 * (BM + BN) * 128 + (EPI == 3 ? BM * 8 : 0)];
+    gemm_bf16_pipe_tile<BM, BN, WM, WN, NLB, A_MODE, B_MODE, C_F32, DBG, EPI>(g, tiles_n, tiles_mn, kt_total, blockIdx.x, gridDim.x, smem_raw);
+}
+
+// Every layer's weight gradient dW_l = dA_l^T H_l (both operands k-strided, fp32 straight into the gradient vector, K = the whole
+// batch: NO split-K slabs, no reduce pass, sum g^2 from the epilogue) in ONE launch of 256 x 192 tiles: workgroup -> (GEMM, tile)
+// by the prefix sums of the descriptor block.  C3: 10 x 48 tiles of 128 K-tiles each on 256 CUs; the long K loop runs at the
+// rate DESIGN.md section 5 measured for K = 24576 (fixed costs amortised), where the per-layer launches (K = 1638 per workgroup
+// after a 5-way split) pay pipeline fill, epilogue and a 47 MB slab round trip per layer.
+__global__ __launch_bounds__(512, 2) void gemm_bf16_pipe_grouped_kernel(GemmBf16Group grp) {
+    constexpr int BM = 256, BN = 192;
+    __shared__ __attribute__((aligned(16))) char smem_raw[2 * (BM + BN) * 128];
+    int j = 0;
+    while (j + 1 < grp.n && (int)blockIdx.x >= grp.wg_begin[j + 1]) ++j;
+    const GemmBf16& g = grp.g[j];
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    gemm_bf16_pipe_tile<BM, BN, 4, 2, 4, OP_KS, OP_KS, true, 0, 0>(g, tiles_n, tiles_m * tiles_n, g.K / BK, (int)blockIdx.x - grp.wg_begin[j],
+                                                                   grp.wg_begin[j + 1] - grp.wg_begin[j], smem_raw);
 }
 
 template <int BM, int BN, int WM, int WN, int NLB>
@@ -680,6 +704,29 @@ int launch_pipe_mid(const GemmBf16& g, hipStream_t s) {
         hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, 4, 2, 4, OP_KC, OP_KC, false, 0, 2>), grid, block, 0, s, g, tiles_n, tiles_m * tiles_n, g.K / BK);
     else
         hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, 4, 2, 4, OP_KC, OP_KC, false, 0, 1>), grid, block, 0, s, g, tiles_n, tiles_m * tiles_n, g.K / BK);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+// all weight gradients of a step in one launch (see gemm_bf16_pipe_grouped_kernel); fills grp.wg_begin
+int gemm_bf16_pipe_grouped(GemmBf16Group& grp, hipStream_t s) {
+    CODAE_REQUIRE(grp.n >= 1 && grp.n <= CODAE_GROUP_MAX, "gemm_bf16_pipe_grouped: %d GEMMs", grp.n);
+    int total = 0;
+    for (int j = 0; j < grp.n; ++j) {
+        const GemmBf16& g = grp.g[j];
+        CODAE_REQUIRE(g.a_mode == OP_KS && g.b_mode == OP_KS && g.c_f32 && g.split_k == 1 && g.K % BK == 0 && g.K >= BK && g.M % 8 == 0 &&
+                          g.N % 8 == 0 && g.M >= 8 && g.N >= 8 && !g.loss.enabled && g.relu_src == nullptr && g.colsum_part == nullptr &&
+                          g.bias == nullptr && !g.relu && (g.lda % 8) == 0 && (g.ldb % 8) == 0 && (g.ldc % 4) == 0,
+                      "gemm_bf16_pipe_grouped: GEMM %d is not a plain unsplit weight-gradient form", j);
+        CODAE_REQUIRE((int64_t)g.K * g.lda * 2 < (int64_t)1 << 32 && (int64_t)g.K * g.ldb * 2 < (int64_t)1 << 32,
+                      "gemm_bf16_pipe_grouped: operand larger than 4 GiB");
+        CODAE_REQUIRE((reinterpret_cast<uintptr_t>(g.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(g.B) & 15) == 0 &&
+                          (reinterpret_cast<uintptr_t>(g.C) & 15) == 0, "gemm_bf16_pipe_grouped: operands must be 16-byte aligned");
+        grp.wg_begin[j] = total;
+        total += ((g.M + 255) / 256) * ((g.N + 191) / 192);
+    }
+    grp.wg_begin[grp.n] = total;
+    hipLaunchKernelGGL(gemm_bf16_pipe_grouped_kernel, dim3(total), dim3(512), 0, s, grp);
     CODAE_LAUNCH_CHECK();
     return CODAE_OK;
 }

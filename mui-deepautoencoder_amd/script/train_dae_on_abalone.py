@@ -108,15 +108,16 @@ def main():
     epochs = args.epochs if args.epochs is not None else mc["EPOCH"]
 
     def sweep(sampler, n_rows, train):
-        """every observation under every C(n, <=k) corruption once (reference :200-236 / :276-314)"""
-        f_k = np.zeros((args.nb_missing, n_var))
-        p_k = np.zeros((args.nb_missing, n_var))
-        f = p = 0
+        """every observation under every C(n, <=k) corruption once (reference :200-236 / :276-314).  Nothing crosses to the host
+        inside the loops: the batch is a device index vector, masks come from the Corrupter's device tables, and the per-step
+        accounting of the reference (monitor criterion, get_partial, get_per_k: :227-236) is one kernel adding into fp64 tables
+        that are read once per sweep."""
         for run in range(corrupter.nb_run):
             for batch_indices in sampler:
-                idx = batch_indices.tolist()
-                input_data = dataset.data[batch_indices.to(device)]
-                masks, fmask = corrupter.get_masks(idx, run)
+                rows = batch_indices.to(device)
+                input_data = dataset.data[rows]
+                ids = corrupter.mask_ids(rows, run)
+                masks, fmask = corrupter.get_masks(rows, run)
                 output_data = model(model.corrupt(input_data=input_data, mask=fmask))
                 if train:
                     loss = full_criterion(x=input_data, y=output_data)
@@ -125,16 +126,8 @@ def main():
                     if mc["TRUNK_GRAD"]:
                         torch.nn.utils.clip_grad_norm_(model.parameters(), 1)
                     optimizer.step()
-                x = input_data.clone()
-                y = output_data.detach().clone()
-                x[:, n_onehot:] = tensor_normazer.undo(x[:, n_onehot:])
-                y[:, n_onehot:] = tensor_normazer.undo(y[:, n_onehot:])
-                loss = monitor(x, y, as_numpy=True)
-                f += np.sum(loss)
-                f_k += monitor.get_per_k(loss, masks)
-                loss = monitor.get_partial(loss, fmask)
-                p += np.sum(loss)
-                p_k += monitor.get_per_k(loss, masks)
+                monitor.accumulate(input_data, output_data, ids, corrupter, normalizer=tensor_normazer, first_scaled_column=n_onehot)
+        f, p, f_k, p_k = monitor.accumulated()
         for i in range(len(per_k)):
             f_k[i, :] /= n_rows * sum(per_k[:i + 1])
             p_k[i, :] /= n_rows * sum(per_k[:i + 1]) / dataset.nb_predictor

@@ -358,6 +358,98 @@ def test_combined_criterion_kernels_match_oracle():
         assert isinstance(full, np.ndarray) and close(full, O.combined_full(arch, x, y))
 
 
+def test_monitor_accumulate_matches_the_reference_accounting():
+    """codae_monitor_accumulate = the per-step accounting of script/train_dae_on_abalone.py:227-236 of the reference (monitor
+    criterion of the de-normalised batch, get_partial, two get_per_k, four running sums) in one launch on fp64 device tables:
+    against the oracle's combined_full / get_per_k / get_partial / normalizer_undo on the abalone fixture's data, masks of
+    k = 1 and k = 2 mixed, several batches accumulated, ragged batch sizes; and the same bits on a second pass."""
+    from golden_util import Golden
+    from codae.tool import CombinedCriterion
+    from oracle import dae_oracle as O
+    g = Golden("abalone_k2")
+    arch = g.meta["arch"]
+    nv, k_max, io = len(arch), 2, 11
+    bm, per_run, _ = O.corrupter_tables(arch, k_max)
+    T = O.mask_transformation(g["type_mask"], nv)
+    rng = np.random.default_rng(12)
+    n_onehot = arch[0]["size"]
+    scale = (rng.random(io - n_onehot) * 5 + 0.5).astype(np.float32)
+    dmin = rng.standard_normal(io - n_onehot).astype(np.float32)
+
+    class Corr:
+        mask_table_u8 = torch.tensor(bm).to(torch.uint8).contiguous().to(dev())
+        k_of_mask_i32 = torch.tensor(per_run, dtype=torch.int32, device=dev())
+
+    class Norm:
+        pass
+    Norm.scale = torch.tensor(scale); Norm.min = torch.tensor(dmin)
+    mon = CombinedCriterion(arch, k_max, dev(), torch.tensor(g["type_mask"]), reduction="none")
+    f = p = 0.0
+    f_k = np.zeros((k_max, nv)); p_k = np.zeros((k_max, nv))
+    batches = []
+    for B in (1, 64, 37, 300):
+        x = g["data"][rng.permutation(len(g["data"]))[:B]]
+        y = (x + 0.3 * rng.standard_normal((B, io))).astype(np.float32)
+        ids = rng.integers(0, len(bm), B).astype(np.int32)
+        batches.append((x, y, ids))
+        xu, yu = x.copy(), y.copy()
+        xu[:, n_onehot:] = O.normalizer_undo(x[:, n_onehot:], scale, dmin)
+        yu[:, n_onehot:] = O.normalizer_undo(y[:, n_onehot:], scale, dmin)
+        loss = O.combined_full(arch, xu, yu)
+        fm = bm[ids]
+        masks = [fm * (per_run[ids] == k + 1)[:, None].astype(np.float32) for k in range(k_max)]
+        f += float(np.sum(loss)); f_k += O.get_per_k(loss, masks, T)
+        part = O.get_partial(loss, fm, T)
+        p += float(np.sum(part)); p_k += O.get_per_k(part, masks, T)
+    outs = []
+    for _ in range(2):
+        for x, y, ids in batches:
+            mon.accumulate(torch.tensor(x, device=dev()), torch.tensor(y, device=dev()), torch.tensor(ids, device=dev()), Corr,
+                           normalizer=Norm, first_scaled_column=n_onehot)
+        outs.append(mon.accumulated())
+    gf, gp, gfk, gpk = outs[0]
+    assert abs(gf - f) <= 1e-5 * f and abs(gp - p) <= 1e-5 * p, (gf, f, gp, p)
+    assert np.allclose(gfk, f_k, rtol=1e-5, atol=1e-6) and np.allclose(gpk, p_k, rtol=1e-5, atol=1e-6)
+    assert float(gpk.sum()) > 0 and float(gfk[1].sum()) > 0                     # both k rows and the partial tables are exercised
+    assert outs[1][0] == gf and outs[1][1] == gp and np.array_equal(outs[1][2], gfk) and np.array_equal(outs[1][3], gpk)
+    assert mon.accumulated()[0] == 0.0                                          # reset
+
+
+def test_ranking_loss_batched_never_counts_exact_copies_of_the_own_row():
+    """the sample's own similarity (a wave sum) and the GEMM's columns are summed in different orders, so an
+    inventory row that is an exact COPY of the sample's own row could be counted or not by an ulp; the reference never counts
+    it (both values come out of one cosine_similarity call: s[idx] > s[j] is false for equal values).  The batched kernel
+    skips such rows by identity (val_group).  Inventory with every validation row duplicated 3x vs the oracle."""
+    from codae.tool import RankingLoss
+    from oracle import dae_oracle as O
+    S, E, N = 3, 32, 240
+    rng = np.random.default_rng(31)
+    base = rng.standard_normal((S, N // 3, E)).astype(np.float32)
+    inv = np.concatenate([base, base, base], axis=1)                       # rows r, r + 80, r + 160 are identical
+    val = [int(v) for v in rng.permutation(N)[:150]]
+    bm, per_run, _ = O.corrupter_tables([{"size": E, "position": s * E} for s in range(S)], 1)
+    mtu = rng.integers(0, S, (N, 1)).astype(np.int32)
+
+    class DS:
+        nb_predictor, nb_used_category, embedding_size = S * E, S, E
+        data_per_category = {c: torch.tensor(inv[c]) for c in range(S)}
+
+    class Corr:
+        mask_table_u8 = torch.tensor(bm).to(torch.uint8).contiguous().to(dev())
+        mask_to_use_i32 = torch.tensor(mtu).contiguous().to(dev())
+    rl = RankingLoss(DS(), val, device=dev())
+    idx = np.asarray(val[:96])
+    # predictions close to the own row: the copies' similarities equal the own one to the last bit or differ by an ulp
+    pred = np.concatenate([inv[c][idx] for c in range(S)], axis=1) + 1e-3 * rng.standard_normal((len(idx), S * E)).astype(np.float32)
+    pred = pred.astype(np.float32)
+    _, fm = O.get_masks(bm, per_run, mtu, 1, idx, 0)
+    ref = O.ranking_loss(pred, fm, idx, [inv[c] for c in range(S)], E, val)
+    rl.add(torch.tensor(pred, device=dev()), torch.tensor(idx, dtype=torch.int32, device=dev()), Corr, run=0, chunk=64)
+    got = rl.total()
+    assert rl._val_group is not None
+    assert abs(got - ref) <= 1e-9 + 1e-6 * abs(ref), (got, ref)            # no slack for flipped comparisons: there are none
+
+
 def test_ranking_loss_kernel_matches_oracle():
     from golden_util import Golden
     from codae.tool import RankingLoss

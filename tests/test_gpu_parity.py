@@ -626,20 +626,24 @@ C3_STEP_BOUNDS = {"f32": {"db": 1e-3, "dW": 2.5e-3, "dW_elem": 5e-3, "m": 1e-3, 
                   "bf16": {"db": 3e-2, "dW": 4e-2, "dW_elem": 1e-1, "m": 4e-2, "W": 2.5e-5, "b": 2.5e-5}}
 
 
-def test_full_size_c3_gradient_is_additive_over_row_shards():
+def test_full_size_c3_gradient_is_additive_over_row_shards(monkeypatch):
     """BASELINE config C3 (10 x Linear(1536,1536), batch 8192, bf16) through a size-independent property: with the loss
     scaled by the GLOBAL batch, grad(full batch) = grad(first half) + grad(second half) — what the data-parallel
     sharding relies on.  Rows are independent in the forward, so the only differences are fp32 summation order in the
-    weight-gradient GEMM (split-K ranges move) and of the bias partial sums.  Also: the bucketed no-join backward
-    (codae_step_backward_async) must give the joined backward's gradients EXACTLY, bias block included (no atomics)."""
+    weight-gradient GEMM and of the bias partial sums.
+
+    Two backward schedules exist at this shape and both are exercised: the single-GPU step's (data-gradient chain, then every
+    weight gradient in ONE grouped launch with unsplit K) and the data-parallel step's (per-layer split-K weight gradients on the
+    side stream, issued bucket by bucket without joins: codae_step_backward_async).  Each is bit-reproducible; the bucketed
+    no-join backward gives the joined per-layer backward's gradients EXACTLY, bias block included (no atomics); the two schedules
+    agree to fp32 summation order."""
     from codae.hip.engine import DaeEngine
     S, E, B, L = 3, 512, 8192, 10
     io = S * E
     g = torch.Generator(device="cpu").manual_seed(21)
     relu = [True] * 4 + [False] + [True] * 4 + [False]
-    eng = DaeEngine([(io, io, r) for r in relu], B, "bf16", DEV)
     lim = (6.0 / (2 * io)) ** 0.5
-    eng.load_params([((torch.rand(io, io, generator=g) * 2 - 1) * lim, torch.zeros(io)) for _ in range(L)])
+    init = [((torch.rand(io, io, generator=g) * 2 - 1) * lim, torch.zeros(io)) for _ in range(L)]
     data = torch.rand(B + 64, io, generator=g).to(DEV)
     table = torch.ones(S, io, dtype=torch.uint8)
     for s in range(S):
@@ -647,9 +651,13 @@ def test_full_size_c3_gradient_is_additive_over_row_shards():
     table = table.to(DEV)
     mask_id = torch.randint(0, S, (B,), generator=g, dtype=torch.int32).to(DEV)
     rows = torch.randperm(B + 64, generator=g)[:B].to(torch.int32).to(DEV)
-    hyper = eng.hyper(1e-5, 1e-4, clip=1.0, global_rows=B)
 
-    def grads_of(lo, hi, buckets=None):
+    def make_engine():
+        eng = DaeEngine([(io, io, r) for r in relu], B, "bf16", DEV)
+        eng.load_params(init)
+        return eng, eng.hyper(1e-5, 1e-4, clip=1.0, global_rows=B)
+
+    def grads_of(eng, hyper, lo, hi, buckets=None):
         batch = eng.make_batch(data, rows[lo:hi].contiguous(), mask_id[lo:hi].contiguous(), table)
         eng.step_forward_loss(batch, hyper)
         if buckets is None:
@@ -661,16 +669,24 @@ def test_full_size_c3_gradient_is_additive_over_row_shards():
         torch.cuda.synchronize()
         return eng.grads.clone()
 
-    full = grads_of(0, B)
+    eng, hyper = make_engine()                                # the single-GPU schedule (grouped unsplit weight gradients)
+    full = grads_of(eng, hyper, 0, B)
     nw = eng.b_off[0]                                   # weights first, then the bias block
     assert float(full[:nw].abs().max()) > 0 and bool(torch.isfinite(full).all())
-    bucketed = grads_of(0, B, buckets=[(6, 10), (3, 6), (1, 3), (0, 1)])
-    assert torch.equal(full, bucketed)
-    assert torch.equal(full, grads_of(0, B))                  # and the same bits on a second run
-    halves = grads_of(0, B // 2) + grads_of(B // 2, B)
+    assert torch.equal(full, grads_of(eng, hyper, 0, B))      # the same bits on a second run
+    bucketed = grads_of(eng, hyper, 0, B, buckets=[(6, 10), (3, 6), (1, 3), (0, 1)])
+    assert torch.equal(bucketed, grads_of(eng, hyper, 0, B, buckets=[(6, 10), (3, 6), (1, 3), (0, 1)]))
     scale = float(full[:nw].abs().max())
+    assert float((full[:nw] - bucketed[:nw]).abs().max()) <= 1e-5 * scale + 1e-3 * float((full[:nw] - 0).abs().mean())
+    assert torch.equal(full[nw:], bucketed[nw:])              # (bias gradients: the same partial rows in the same order)
+    halves = grads_of(eng, hyper, 0, B // 2) + grads_of(eng, hyper, B // 2, B)
     assert float((full[:nw] - halves[:nw]).abs().max()) <= 2e-3 * scale
     assert float((full[nw:] - halves[nw:]).abs().max()) <= 2e-3 * float(full[nw:].abs().max())
+    del eng
+    monkeypatch.setenv("CODAE_NO_DEFER_WGRAD", "1")           # (read at codae_create) round 2's joined per-layer backward
+    eng2, hyper2 = make_engine()
+    joined = grads_of(eng2, hyper2, 0, B)
+    assert torch.equal(joined, bucketed)
 
 
 def test_full_size_c5_step_properties():

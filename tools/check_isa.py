@@ -74,8 +74,15 @@ def demangle(names):
     out = {}
     for n in names:
         m = re.search(r"(gemm_bf16(?:_pipe|_snake)?_kernel)I((?:L[ib]\d+E)+)E", n)
+        mg = re.search(r"gemm_bf16_grouped_kernelILi(\d+)ELi(\d+)EE", n)
         if m:
             out[n] = "%s<%s>" % (m.group(1), ", ".join(re.findall(r"L[ib](\d+)E", m.group(2))))
+        elif "gemm_bf16_pipe_grouped_kernel" in n:
+            # every weight gradient of a step in one launch: the 256 x 192 pipelined tile, both operands k-strided, fp32 out
+            out[n] = "gemm_bf16_pipe_kernel<256, 192, 4, 2, 4, 1, 1, 1, 0, 0>"
+        elif mg:
+            # grouped weight gradients of narrow stacks: the one-barrier tile, 2 x 2 waves, both operands k-strided, fp32 out
+            out[n] = "gemm_bf16_kernel<%s, %s, 2, 2, 1, 1, 1, 0, 2>" % (mg.group(1), mg.group(2))
         else:
             out[n] = n
     return out
