@@ -116,8 +116,11 @@ class DataParallel:
     step_forward_loss(batch, hyper), step_backward(B, lo, hi), step_update(hyper).
     """
 
-    def __init__(self, engine, process_group=None, n_buckets=4, sharded=False):
-        """n_buckets: 1 .. engine.L (= one bucket per layer); sharded: see the module docstring."""
+    def __init__(self, engine, process_group=None, n_buckets=None, sharded=False):
+        """n_buckets: 1 .. engine.L; None = one bucket per layer (the first collective starts one layer into the
+        backward, the exposed tail is one layer's gradient); sharded: see the module docstring."""
+        if n_buckets is None:
+            n_buckets = engine.L
         import torch.distributed as dist
         self.dist = dist
         self.engine = engine
@@ -306,7 +309,7 @@ class HipEmbeddingTrainer:
     """Owns a DaeEngine, the resident dataset and the mask tables; runs train / eval steps."""
 
     def __init__(self, schedule, data, mask_table_u8, mask_to_use_i32, lr, weight_decay, clip=1.0,
-                 max_batch=8192, precision="bf16", device="cuda:0", distributed=False, n_buckets=4, use_graph=False,
+                 max_batch=8192, precision="bf16", device="cuda:0", distributed=False, n_buckets=None, use_graph=False,
                  sharded_update=False):
         """use_graph: replay the fused step from a hipGraph (codae_train_step_graph): for launch-bound shapes
         (small batches); single process only - the bucketed data-parallel step is not captured."""

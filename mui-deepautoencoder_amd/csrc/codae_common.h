@@ -92,6 +92,7 @@ struct EnvToggles {
     bool side_priority_set = false; int side_priority = 0;   // CODAE_SIDE_PRIORITY
     bool no_wt = false, single_stream = false, tail_on_side = false, no_fused_loss = false, flat_adam = false,
          no_fused_norm = false, no_chain = false, no_deep_small = false,      // CODAE_NO_DEEP_SMALL: 2-stage small GEMMs
+         no_prefetch = false,         // CODAE_NO_PREFETCH: no touch of the next launch's weights under the epilogue
          no_defer_wgrad = false;      // CODAE_NO_DEFER_WGRAD: per-layer split-K weight gradients beside the data-gradient chain (round 2's backward)
 };
 const EnvToggles& env();
@@ -153,6 +154,9 @@ struct GemmBf16 {
     int split_k;             // >1: fp32 partial slabs C + z*M*ldc, K range split evenly in BK units
     LossFuse loss;           // enabled: C receives dy (bf16), colsum_part the last bias gradient's partial sums
     int dbg;                 // timing-only ablations (CODAE_GEMM_DBG): 1 no LDS-DMA, 2 no MFMA, 4 no epilogue stores
+    const void* prefetch; int64_t prefetch_bytes;   // pipelined 256 x 192 kernel only: touched (one 4-B load per 128-B line, spread
+                             // over the launch's workgroups) while the epilogue runs - the NEXT launch's weight matrix, which
+                             // would otherwise come from HBM under its first K-tiles; null = nothing
     double* sumsq_slots;     // fp32 output, 128 x 128 tile only: += sum of the stored values' squares, scattered over the
                              // CODAE_S_N_SLOTS clip_grad_norm_ slots (what sumsq_kernel would add in a pass of its own), or null
 };

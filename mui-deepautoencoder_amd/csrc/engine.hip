@@ -41,6 +41,7 @@ void env_reload() {
     e.no_chain = getenv("CODAE_NO_CHAIN") != nullptr;
     e.no_deep_small = getenv("CODAE_NO_DEEP_SMALL") != nullptr;
     e.no_defer_wgrad = getenv("CODAE_NO_DEFER_WGRAD") != nullptr;
+    e.no_prefetch = getenv("CODAE_NO_PREFETCH") != nullptr;
     if (const char* k = getenv("CODAE_SMALL_TILE_MAX")) e.small_tile_max = atoi(k);
     if (const char* k = getenv("CODAE_SMALL_STAGES")) e.small_stages = atoi(k) == 2 ? 2 : 4;
     g_env = e;
@@ -391,6 +392,10 @@ int run_linear(const codae_engine* e, const codae_buffers* b, int l, const void*
         g.M = rows; g.N = N; g.K = K;
         g.bias = b->params + e->b_off[l]; g.relu = e->relu[l];
         g.split_k = 1;
+        if (l + 1 < e->L && !e->cfg.no_prefetch) {        // the next layer's weights, touched under this launch's epilogue
+            g.prefetch = reinterpret_cast<const bf16_t*>(b->shadow_w) + e->w_off[l + 1];
+            g.prefetch_bytes = (int64_t)e->in[l + 1] * e->out[l + 1] * 2;
+        }
         return gemm_bf16(g, s);
     }
     GemmF32 g{};
@@ -479,6 +484,10 @@ int run_dgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, fl
             if (e->relu[l - 1]) { g.relu_src = reinterpret_cast<const bf16_t*>(act_ptr(e, b, l)); g.ld_relu = K; }
             g.colsum_part = part_ptr(e, b, l - 1);
             e->parts_pending[l - 1] = gemm_bf16_colsum_rows(g);
+            if (b->shadow_wt != nullptr && l >= 2 && !e->cfg.no_wt && !e->cfg.no_prefetch) {      // the next data gradient's operand
+                g.prefetch = reinterpret_cast<const bf16_t*>(b->shadow_wt) + e->w_off[l - 1];
+                g.prefetch_bytes = (int64_t)e->in[l - 1] * e->out[l - 1] * 2;
+            }
         }
         return gemm_bf16(g, s);
     }
@@ -926,6 +935,10 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
             g.loss.mask_to_use = batch->mask_to_use; g.loss.nb_run = batch->nb_run; g.loss.run = batch->run;
             g.loss.table = batch->mask_table; g.loss.io = batch->io; g.loss.B = B; g.loss.inv_n = (float)(1.0 / n_glob);
             g.loss.parts = loss_parts_ptr(h, b);
+            if (b->shadow_wt != nullptr && l >= 1 && !h->cfg.no_wt && !h->cfg.no_prefetch) {     // the first data gradient's operand
+                g.prefetch = reinterpret_cast<const bf16_t*>(b->shadow_wt) + h->w_off[l];
+                g.prefetch_bytes = (int64_t)h->in[l] * h->out[l] * 2;
+            }
             const int n_loss_parts = gemm_bf16_loss_parts(g);
             CODAE_REQUIRE(n_loss_parts <= h->loss_part_cap, "fused loss: %d workgroups exceed the partial-sum rows (%d)", n_loss_parts, h->loss_part_cap);
             {

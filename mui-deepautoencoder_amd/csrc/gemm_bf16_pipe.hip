@@ -303,6 +303,22 @@ __device__ __forceinline__ void gemm_bf16_pipe_tile(const GemmBf16& g, int tiles
 
     // ---- epilogue: lane holds C[i][j .. j+3] of each 16 x 16 tile (swapped MFMA operands)
     const int li = lane & 15, g4 = (lane >> 4) * 4;
+    // the next launch's weights: this workgroup's share of the matrix, one 4-B load per 128-B line, issued now and consumed
+    // (by a store that never happens) after the epilogue's own stores - its whole latency lies under the epilogue
+    uint32_t pf_val = 0;
+    if (g.prefetch != nullptr) {
+        const int64_t lines = (g.prefetch_bytes + 127) >> 7;
+        const int64_t per_wg = (lines + nwg - 1) / nwg;
+        for (int64_t i = threadIdx.x; i < per_wg; i += 64 * NW) {
+            const int64_t mine = (int64_t)wg * per_wg + i;
+            if (mine < lines) pf_val ^= *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(g.prefetch) + (mine << 7));
+        }
+    }
+    // (consumed by a store whose condition is never true - prefetch_bytes is positive - so the compiler keeps the loads and
+    // waits for them only at the kernel's exit)
+    auto consume_prefetch = [&]() {
+        if (g.prefetch != nullptr && pf_val == 0xFFA5FFA5u && g.prefetch_bytes < 0) *reinterpret_cast<volatile uint32_t*>(g.C) = pf_val;
+    };
     phase_barrier();          // every wave is past its last fragment read and every DMA has landed: LDS is free
     if constexpr (EPI == 3) {
         // Last forward layer of a training step (train_dae_on_embedding.py:206-223): y = acc + bias stays in registers.
@@ -463,6 +479,7 @@ __device__ __forceinline__ void gemm_bf16_pipe_tile(const GemmBf16& g, int tiles
                 if (j0 + col < g.N) g.colsum_part[(int64_t)tm * g.N + j0 + col] = sum;
             }
         }
+        consume_prefetch();
         return;
     }
     if constexpr (!C_F32 && !dbg_nostore) {
@@ -561,6 +578,7 @@ __device__ __forceinline__ void gemm_bf16_pipe_tile(const GemmBf16& g, int tiles
                 if (j0 + col < g.N) g.colsum_part[(int64_t)tm * g.N + j0 + col] = sum;
             }
         }
+        consume_prefetch();
         return;
     }
     // fp32 output (split-K slabs of the weight gradient, fp32 y): staged through LDS like the bf16 path, in the two

@@ -1,6 +1,6 @@
 """profiles/hbm_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py.
 
-Usage: python tools/hbm_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [workload key] [out.json]
+Usage: python tools/hbm_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [workload key] [out.json] [GEMMs per grouped launch]
 (workload key as bench.py builds it: "<slots>x<emb>_b<batch>_<precision>", default 3x512_b8192_bf16; the entry of that
 workload is replaced, other workloads in the file are kept)
 bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (MI355X_MICROARCH.md, HBM section: FETCH_SIZE / WRITE_SIZE are
@@ -24,6 +24,8 @@ def per_kernel(path, counter):
 
 
 def classify(name):
+    if "gemm_bf16_pipe_grouped" in name:
+        return "gemm_wgrad_grouped"            # every layer's weight gradient in one launch
     if "gemm_bf16_pipe_kernel" in name:
         args = name[name.index("<") + 1:name.index(">")].replace(" ", "").split(",")
         a_mode, b_mode, c_f32, epi = args[5], args[6], args[7], args[9] if len(args) > 9 else "0"
@@ -52,6 +54,10 @@ def main():
         out[cls] = {"bytes_per_launch": (2.0 * f + w) * 1024.0, "read": 2.0 * f * 1024.0, "written": w * 1024.0,
                     "launches_sampled": nf[name]}
     res = {k: v["bytes_per_launch"] for k, v in out.items() if k.startswith("gemm_") or k in ("loss_gemm", "chain", "wgrad_grouped")}
+    n_grouped = int(sys.argv[5]) if len(sys.argv) > 5 else 10
+    if "gemm_wgrad_grouped" in res:
+        # bench.py reports the grouped launch as n_grouped launches of elapsed / n_grouped each: the same unit here
+        res["gemm_wgrad"] = res["gemm_wgrad_grouped"] / n_grouped
     res["loss"] = res.get("loss_gemm")
     res["_detail"] = out
     res["_unit"] = ("bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts half of wide "

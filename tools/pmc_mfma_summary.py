@@ -5,7 +5,7 @@
             was busy (the counter is MFMA-busy SIMD-cycles summed over the chip)
   achieved = algorithmic flops / duration
 
-Usage: python tools/pmc_mfma_summary.py <counter_collection.csv> [M N K]   (GEMM shape for the TFLOP/s column)"""
+Usage: python tools/pmc_mfma_summary.py <counter_collection.csv> [M N K [GEMMs per grouped wgrad launch]]   (GEMM shape for the TFLOP/s column)"""
 import csv, sys, collections
 
 path = sys.argv[1]
@@ -18,7 +18,12 @@ for r in csv.DictReader(open(path)):
     meta[d] = (r["Kernel_Name"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 
 
+N_GROUPED = int(sys.argv[5]) if len(sys.argv) > 5 else 10      # GEMMs inside one grouped weight-gradient launch (C3: 10 layers)
+
+
 def classify(name):
+    if "gemm_bf16_pipe_grouped" in name:
+        return "gemm_wgrad_x%d" % N_GROUPED
     if "gemm_bf16_pipe_kernel" in name:
         a = name[name.index("<") + 1:name.index(">")].replace(" ", "").split(",")
         if a[7] == "true":
@@ -51,4 +56,5 @@ for cls, v in sorted(agg.items()):
     n = len(v)
     dur = sum(x[0] for x in v) / n / 1e3
     print("%-14s %6d %9.1f %8.2f %9.1f%% %9.1f%% %9s" % (cls, n, dur, sum(x[1] for x in v) / n, 100 * sum(x[2] for x in v) / n, 100 * sum(x[3] for x in v) / n,
-                                                   ("%.0f" % (fl / (dur * 1e-6) / 1e12)) if cls.startswith("gemm") or cls == "loss_gemm" else "-"))
+                                                   ("%.0f" % ((N_GROUPED if cls.startswith("gemm_wgrad_x") else 1) * fl / (dur * 1e-6) / 1e12))
+                                                   if cls.startswith("gemm") or cls == "loss_gemm" else "-"))
