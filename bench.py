@@ -258,6 +258,16 @@ def main():
         if prev_ms is not None and abs(ms - prev_ms) <= 0.10 * min(ms, prev_ms) and extra >= 3:
             break
         prev_ms = ms
+    # ... and a sustained burst, still untimed: the FIRST back-to-back run of a process that is the first on a freshly leased
+    # box has been seen to lose ~8 ms somewhere inside (kernel durations unchanged, host enqueue 0.08 ms / step: 1.396 vs 1.236
+    # ms / step over 50 steps, the next process on the same box clean) - the power management settling under its first
+    # sustained load is the working explanation.  64 steps (~80 ms) absorb it; the stall detector below stays as the backstop.
+    burst = 0
+    if not os.environ.get("BENCH_NO_BURST"):
+        burst = 64
+        for i in range(burst):
+            tr.train_batch(idx_steps[i % max(1, args.warmup or 1)], run=0)
+        barrier()
     kernel_events = not args.no_kernel_events and not args.graph
     # at least three timed steps carry the per-launch event pairs (mean != min in by_kernel), spread over the region
     every = max(1, min(args.kernel_events_every, args.steps // 3 if args.steps >= 3 else 1))
@@ -360,7 +370,7 @@ def main():
             "metric": "training samples/sec at 3x512-dim input, batch 8192" if (slots, emb, B) == (S, E, BATCH)
                       else "training samples/sec at %dx%d-dim input, batch %d" % (slots, emb, B),
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "warmup_effective": args.warmup + extra,
+            "warmup_effective": args.warmup + extra + burst,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "embedding.yaml topology: %d slots x %d (io %d), z=io, 4+4 layers -> 10 x Linear(%d,%d); "

@@ -79,8 +79,10 @@ __device__ __forceinline__ void gemm_bf16_pipe_tile(const GemmBf16& g, int tiles
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = w / WN, wc = w % WN;
 
+    // XCD-aware remap (workgroup b of a launch runs on XCD b % 8): consecutive tile ids - the tiles of one A row panel, then of
+    // the next - go to ONE XCD's L2.  nwg <= 0: `wg` already is the tile id (the grouped launch remaps over ALL its GEMMs).
     int bid = wg;
-    {
+    if (nwg > 0) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
@@ -661,12 +663,22 @@ void gemm_bf16_pipe_kernel(GemmBf16 g, int tiles_n, int tiles_mn, int kt_total) 
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pipe_grouped_kernel(GemmBf16Group grp) {
     constexpr int BM = 256, BN = 192;
     __shared__ __attribute__((aligned(16))) char smem_raw[2 * (BM + BN) * 128];
+    // Workgroup b runs on XCD b % 8, the s-th of that XCD's workgroups (s = b / 8).  Each XCD takes a CONTIGUOUS eighth of the
+    // launch's tile list (GEMM after GEMM, row panel after row panel), so that the 32 workgroups an XCD runs at a time are 4
+    // consecutive row panels x all column tiles of ONE weight gradient: they share 4 dA strips and the layer's 8 H strips in that
+    // XCD's L2.  (Remapped per GEMM, as a plain launch does, an XCD held 6 tiles of each of 5 layers at a time and every tile
+    // streamed its own H strip from HBM: 2.25 GB read per launch for 0.5 GB of operands, the launch ran at the HBM roofline.)
+    const int total = grp.wg_begin[grp.n];
+    int t = (int)blockIdx.x;
+    {
+        const int q = total >> 3, r = total & 7, xcd = t & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
+    }
     int j = 0;
-    while (j + 1 < grp.n && (int)blockIdx.x >= grp.wg_begin[j + 1]) ++j;
+    while (j + 1 < grp.n && t >= grp.wg_begin[j + 1]) ++j;
     const GemmBf16& g = grp.g[j];
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-    gemm_bf16_pipe_tile<BM, BN, 4, 2, 4, OP_KS, OP_KS, true, 0, 0>(g, tiles_n, tiles_m * tiles_n, g.K / BK, (int)blockIdx.x - grp.wg_begin[j],
-                                                                   grp.wg_begin[j + 1] - grp.wg_begin[j], smem_raw);
+    gemm_bf16_pipe_tile<BM, BN, 4, 2, 4, OP_KS, OP_KS, true, 0, 0>(g, tiles_n, tiles_m * tiles_n, g.K / BK, t - grp.wg_begin[j], 0, smem_raw);
 }
 
 template <int BM, int BN, int WM, int WN, int NLB>
