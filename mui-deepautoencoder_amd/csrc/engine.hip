@@ -42,6 +42,7 @@ void env_reload() {
     e.no_deep_small = getenv("CODAE_NO_DEEP_SMALL") != nullptr;
     e.no_defer_wgrad = getenv("CODAE_NO_DEFER_WGRAD") != nullptr;
     e.no_prefetch = getenv("CODAE_NO_PREFETCH") != nullptr;
+    e.force_defer_wgrad = getenv("CODAE_DEFER_WGRAD") != nullptr;
     if (const char* k = getenv("CODAE_SMALL_TILE_MAX")) e.small_tile_max = atoi(k);
     if (const char* k = getenv("CODAE_SMALL_STAGES")) e.small_stages = atoi(k) == 2 ? 2 : 4;
     g_env = e;
@@ -339,6 +340,7 @@ bool defer_wgrad_ok(const codae_engine* e, int rows) {
         if (t > largest) largest = t;
         if ((int64_t)rows * e->out[l] * 2 >= (int64_t)1 << 32 || (int64_t)rows * e->in[l] * 2 >= (int64_t)1 << 32) return false;
     }
+    if (e->cfg.force_defer_wgrad) return total >= 200;
     return largest < 160 && total >= 200;
 }
 
