@@ -204,7 +204,8 @@ int chain_rows_per_workgroup();
 int launch_chain_step(const ChainArgs& a, hipStream_t s);
 
 // ---- elementwise / reductions (elementwise.hip) ----------------------------
-int launch_gather_corrupt(const codae_batch* b, void* out, int out_bf16, hipStream_t s);
+// out_ld: row stride of `out` in elements (0 = b->io: contiguous rows)
+int launch_gather_corrupt(const codae_batch* b, void* out, int out_bf16, hipStream_t s, int64_t out_ld = 0);
 int launch_cast_bf16(const float* src, bf16_t* dst, int64_t n, hipStream_t s);
 int launch_corrupt(const float* x, const float* mask, float* out, int64_t n, hipStream_t s);
 int launch_expand_masks(const int32_t* mask_id, const uint8_t* table, const int32_t* k_of_mask, int B, int io,
@@ -213,7 +214,7 @@ int launch_expand_masks(const int32_t* mask_id, const uint8_t* table, const int3
 // [mse_loss_colsum_rows(B)][io] (partial sums of the last bias gradient, one row per block)
 // loss_parts [mse_loss_colsum_rows(B)][2]: per-block metric sums (see LossFuse::parts)
 int launch_mse_loss(const codae_batch* b, const float* y, void* dy, int dy_bf16, float inv_n, float* colsum_part,
-                    double* loss_parts, int want_grad, hipStream_t s);
+                    double* loss_parts, int want_grad, hipStream_t s, int64_t dy_ld = 0);    // dy_ld: row stride of dy (0 = io)
 int mse_loss_colsum_rows(int B);
 int launch_mse_dense(const float* x, const float* y, const float* fmask, float* dy, int64_t n, float inv_n,
                      double* scalars, hipStream_t s);

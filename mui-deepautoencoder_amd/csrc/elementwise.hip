@@ -49,7 +49,7 @@ __global__ __launch_bounds__(NT) void gather_corrupt_bf16x8_kernel(const float* 
                                                                    const uint8_t* __restrict__ table, int B, int io,
                                                                    bf16_t* __restrict__ out,
                                                                    const int32_t* __restrict__ mask_to_use, int nb_run,
-                                                                   int run) {
+                                                                   int run, int64_t out_ld) {
     const bool masked = (mask_id != nullptr) || (mask_to_use != nullptr);
     const int cols = io / 8;
     const int64_t total = (int64_t)B * cols;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(NT) void gather_corrupt_bf16x8_kernel(const float* 
         uint4 o;
         o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
         o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
-        *reinterpret_cast<uint4*>(out + (int64_t)b * io + c) = o;
+        *reinterpret_cast<uint4*>(out + (int64_t)b * out_ld + c) = o;
     }
 }
 
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(NT) void gather_corrupt_kernel(const float* __restr
                                                             const uint8_t* __restrict__ table, int B, int io,
                                                             void* __restrict__ out,
                                                             const int32_t* __restrict__ mask_to_use, int nb_run,
-                                                            int run) {
+                                                            int run, int64_t out_ld) {
     constexpr int W = VEC ? 4 : 1;
     const bool masked = (mask_id != nullptr) || (mask_to_use != nullptr);
     const int cols = io / W;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(NT) void gather_corrupt_kernel(const float* __restr
                 v[0] = table[(int64_t)id * io + c] ? v[0] : 0.f;
             }
         }
-        const int64_t o = (int64_t)b * io + c;
+        const int64_t o = (int64_t)b * out_ld + c;
         if constexpr (OUT_BF16) {
             bf16_t* op = reinterpret_cast<bf16_t*>(out) + o;
             if constexpr (VEC) *reinterpret_cast<uint2*>(op) = pack_bf16x4(v[0], v[1], v[2], v[3]);
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(NT) void mse_loss_kernel(const float* __restrict__ 
                                                       const float* __restrict__ y, void* __restrict__ dy,
                                                       float inv_n, float* __restrict__ colsum_part,
                                                       double* __restrict__ loss_parts, int want_grad,
-                                                      const int32_t* __restrict__ mask_to_use, int nb_run, int run) {
+                                                      const int32_t* __restrict__ mask_to_use, int nb_run, int run, int64_t dy_ld) {
     __shared__ float red[4];
     const bool masked = (mask_id != nullptr) || (mask_to_use != nullptr);
     constexpr int W = VEC ? 4 : 1;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(NT) void mse_loss_kernel(const float* __restrict__ 
                 cs[k] += g[k];
             }
             if (want_grad && live) {
-                const int64_t o = (int64_t)b * io + c;
+                const int64_t o = (int64_t)b * dy_ld + c;
                 if constexpr (DY_BF16) {
                     bf16_t* op = reinterpret_cast<bf16_t*>(dy) + o;
                     if constexpr (VEC) *reinterpret_cast<uint2*>(op) = pack_bf16x4(g[0], g[1], g[2], g[3]);
@@ -609,23 +609,24 @@ inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) ==
 
 }  // namespace
 
-int launch_gather_corrupt(const codae_batch* b, void* out, int out_bf16, hipStream_t s) {
+int launch_gather_corrupt(const codae_batch* b, void* out, int out_bf16, hipStream_t s, int64_t out_ld) {
+    if (out_ld <= 0) out_ld = b ? b->io : 0;
     CODAE_REQUIRE(b && b->data && out && b->B > 0 && b->io > 0, "gather_corrupt: bad batch");
     const bool masked = b->mask_id || b->mask_to_use;
     CODAE_REQUIRE(!masked || b->mask_table, "gather_corrupt: mask ids without mask_table");
     CODAE_REQUIRE(!b->mask_to_use || b->mask_id || (b->nb_run > 0 && b->run >= 0 && b->run < b->nb_run),
                   "gather_corrupt: run %d outside [0, %d)", b->run, b->nb_run);
-    const bool vec = (b->io % 4 == 0) && a16(b->data) && a16(out) && (!masked || (reinterpret_cast<uintptr_t>(b->mask_table) & 3) == 0);
+    const bool vec = (b->io % 4 == 0) && (out_ld % 4 == 0) && a16(b->data) && a16(out) && (!masked || (reinterpret_cast<uintptr_t>(b->mask_table) & 3) == 0);
     const int64_t items = (int64_t)b->B * (vec ? b->io / 4 : b->io);
     const int grid = grid_for(items);
     if (vec && out_bf16 && b->io % 8 == 0 && (!masked || (reinterpret_cast<uintptr_t>(b->mask_table) & 7) == 0)) {
         hipLaunchKernelGGL(gather_corrupt_bf16x8_kernel, dim3(grid_for(items / 2)), dim3(NT), 0, s, b->data, b->row_idx, b->mask_id,
-                           b->mask_table, b->B, b->io, reinterpret_cast<bf16_t*>(out), b->mask_to_use, b->nb_run, b->run);
+                           b->mask_table, b->B, b->io, reinterpret_cast<bf16_t*>(out), b->mask_to_use, b->nb_run, b->run, out_ld);
         CODAE_LAUNCH_CHECK();
         return CODAE_OK;
     }
 #define GC(V, O) hipLaunchKernelGGL((gather_corrupt_kernel<V, O>), dim3(grid), dim3(NT), 0, s, b->data, b->row_idx, \
-                                    b->mask_id, b->mask_table, b->B, b->io, out, b->mask_to_use, b->nb_run, b->run)
+                                    b->mask_id, b->mask_table, b->B, b->io, out, b->mask_to_use, b->nb_run, b->run, out_ld)
     if (vec && out_bf16) GC(true, true);
     else if (vec) GC(true, false);
     else if (out_bf16) GC(false, true);
@@ -669,17 +670,18 @@ int launch_expand_masks(const int32_t* mask_id, const uint8_t* table, const int3
 int mse_loss_colsum_rows(int B) { return (B + LOSS_ROWS - 1) / LOSS_ROWS; }
 
 int launch_mse_loss(const codae_batch* b, const float* y, void* dy, int dy_bf16, float inv_n, float* colsum_part,
-                    double* loss_parts, int want_grad, hipStream_t s) {
+                    double* loss_parts, int want_grad, hipStream_t s, int64_t dy_ld) {
+    if (dy_ld <= 0) dy_ld = b ? b->io : 0;
     CODAE_REQUIRE(b && b->data && y && loss_parts && b->B > 0 && b->io > 0, "mse_loss: bad args");
     CODAE_REQUIRE(!want_grad || dy, "mse_loss: gradient requested without dy");
     const bool masked = b->mask_id || b->mask_to_use;
     CODAE_REQUIRE(!masked || b->mask_table, "mse_loss: mask ids without mask_table");
-    const bool vec = (b->io % 4 == 0) && a16(b->data) && a16(y) && (!dy || a16(dy)) &&
+    const bool vec = (b->io % 4 == 0) && (dy_ld % 4 == 0) && a16(b->data) && a16(y) && (!dy || a16(dy)) &&
                      (!masked || (reinterpret_cast<uintptr_t>(b->mask_table) & 3) == 0);
     const int grid = (b->B + LOSS_ROWS - 1) / LOSS_ROWS;
 #define ML(V, O) hipLaunchKernelGGL((mse_loss_kernel<V, O>), dim3(grid), dim3(NT), 0, s, b->data, b->row_idx, \
                                     b->mask_id, b->mask_table, b->B, b->io, y, dy, inv_n, colsum_part, loss_parts, want_grad, \
-                                    b->mask_to_use, b->nb_run, b->run)
+                                    b->mask_to_use, b->nb_run, b->run, dy_ld)
     if (vec && dy_bf16) ML(true, true);
     else if (vec) ML(true, false);
     else if (dy_bf16) ML(false, true);

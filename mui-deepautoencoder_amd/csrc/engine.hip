@@ -66,6 +66,10 @@ constexpr int CODAE_MAX_DACT = 16;
 struct codae_engine {
     int L = 0;
     std::vector<int> in, out;
+    // row strides of the activation / activation-gradient buffers: bf16 mode pads every width to a multiple of 64 (the K extent of
+    // the GEMM that reads the buffer walks whole 64-deep tiles) with ZERO pad columns - allocated zeroed, never written - so that
+    // whatever the weight operand holds past a row's real width (the head of its next row) is multiplied by 0.  fp32: the width.
+    std::vector<int> in_ld, out_ld;
     std::vector<uint8_t> relu;
     int max_batch = 0, max_rows = 0;  // max_rows = max_batch rounded up to 64
     int prec = CODAE_PREC_F32;
@@ -312,8 +316,8 @@ int run_wgrad_grouped(const codae_engine* e, const codae_buffers* b, int rows, b
         grp.n = 0;
         for (int l = base; l < e->L && grp.n < CODAE_GROUP_MAX; ++l) {
             GemmBf16& g = grp.g[grp.n++];
-            g.A = reinterpret_cast<const bf16_t*>(dact_ptr(e, b, l)); g.lda = e->out[l]; g.a_mode = OP_KS;
-            g.B = reinterpret_cast<const bf16_t*>(act_ptr(e, b, l)); g.ldb = e->in[l]; g.b_mode = OP_KS;
+            g.A = reinterpret_cast<const bf16_t*>(dact_ptr(e, b, l)); g.lda = e->out_ld[l]; g.a_mode = OP_KS;
+            g.B = reinterpret_cast<const bf16_t*>(act_ptr(e, b, l)); g.ldb = e->in_ld[l]; g.b_mode = OP_KS;
             g.C = b->grads + e->w_off[l]; g.ldc = e->in[l]; g.c_f32 = 1;
             g.M = e->out[l]; g.N = e->in[l]; g.K = rows; g.split_k = 1;
             g.sumsq_slots = with_norm ? b->scalars + CODAE_S_GRAD_SQ_SLOTS : nullptr;
@@ -349,8 +353,8 @@ int run_wgrad_deferred(const codae_engine* e, const codae_buffers* b, int rows, 
     grp.n = 0;
     for (int l = e->L - 1; l >= 0; --l) {            // (backward order: the layers whose operands were touched last come first)
         GemmBf16& g = grp.g[grp.n++];
-        g.A = reinterpret_cast<const bf16_t*>(dact_ptr(e, b, l)); g.lda = e->out[l]; g.a_mode = OP_KS;
-        g.B = reinterpret_cast<const bf16_t*>(act_ptr(e, b, l)); g.ldb = e->in[l]; g.b_mode = OP_KS;
+        g.A = reinterpret_cast<const bf16_t*>(dact_ptr(e, b, l)); g.lda = e->out_ld[l]; g.a_mode = OP_KS;
+        g.B = reinterpret_cast<const bf16_t*>(act_ptr(e, b, l)); g.ldb = e->in_ld[l]; g.b_mode = OP_KS;
         g.C = b->grads + e->w_off[l]; g.ldc = e->in[l]; g.c_f32 = 1;
         g.M = e->out[l]; g.N = e->in[l]; g.K = rows; g.split_k = 1;
         g.sumsq_slots = e->norm_in_backward ? b->scalars + CODAE_S_GRAD_SQ_SLOTS : nullptr;
@@ -388,10 +392,11 @@ int run_linear(const codae_engine* e, const codae_buffers* b, int l, const void*
     ProfScope prof(e, CODAE_K_GEMM_FWD, s);
     if (e->prec == CODAE_PREC_BF16) {
         GemmBf16 g{};
-        g.A = reinterpret_cast<const bf16_t*>(x); g.lda = K; g.a_mode = OP_KC;
+        // K = the PADDED input width: the extra k columns are zeros in x (see in_ld) times the head of W's next row
+        g.A = reinterpret_cast<const bf16_t*>(x); g.lda = e->in_ld[l]; g.a_mode = OP_KC;
         g.B = reinterpret_cast<const bf16_t*>(b->shadow_w) + e->w_off[l]; g.ldb = K; g.b_mode = OP_KC;
-        g.C = y; g.ldc = N; g.c_f32 = y_f32 ? 1 : 0;
-        g.M = rows; g.N = N; g.K = K;
+        g.C = y; g.ldc = y_f32 ? N : e->out_ld[l]; g.c_f32 = y_f32 ? 1 : 0;
+        g.M = rows; g.N = N; g.K = e->in_ld[l];
         g.bias = b->params + e->b_off[l]; g.relu = e->relu[l];
         g.split_k = 1;
         if (l + 1 < e->L && !e->cfg.no_prefetch) {        // the next layer's weights, touched under this launch's epilogue
@@ -416,8 +421,8 @@ int run_wgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, hi
     if (e->prec == CODAE_PREC_BF16) {
         const int S = e->split_k[l] <= rows / 64 ? e->split_k[l] : rows / 64;
         GemmBf16 g{};
-        g.A = reinterpret_cast<const bf16_t*>(dact_ptr(e, b, l)); g.lda = N; g.a_mode = OP_KS;
-        g.B = reinterpret_cast<const bf16_t*>(act_ptr(e, b, l)); g.ldb = K; g.b_mode = OP_KS;
+        g.A = reinterpret_cast<const bf16_t*>(dact_ptr(e, b, l)); g.lda = e->out_ld[l]; g.a_mode = OP_KS;
+        g.B = reinterpret_cast<const bf16_t*>(act_ptr(e, b, l)); g.ldb = e->in_ld[l]; g.b_mode = OP_KS;
         g.M = N; g.N = K; g.K = rows;
         g.ldc = K; g.c_f32 = 1; g.split_k = S;
         if (S > 1) {
@@ -470,20 +475,20 @@ int run_dgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, fl
     ProfScope prof(e, CODAE_K_GEMM_DGRAD, s);
     if (e->prec == CODAE_PREC_BF16) {
         GemmBf16 g{};
-        g.A = reinterpret_cast<const bf16_t*>(dact_ptr(e, b, l)); g.lda = N; g.a_mode = OP_KC;
+        g.A = reinterpret_cast<const bf16_t*>(dact_ptr(e, b, l)); g.lda = e->out_ld[l]; g.a_mode = OP_KC;
         if (b->shadow_wt != nullptr && l >= 1 && !e->cfg.no_wt) {
             // dx[m][k] = sum_n dy[m][n] Wt[k][n]: both operands k-contiguous -> the forward-form kernel
             g.B = reinterpret_cast<const bf16_t*>(b->shadow_wt) + e->w_off[l]; g.ldb = N; g.b_mode = OP_KC;
         } else {
             g.B = reinterpret_cast<const bf16_t*>(b->shadow_w) + e->w_off[l]; g.ldb = K; g.b_mode = OP_KS;
         }
-        g.M = rows; g.N = K; g.K = N;
+        g.M = rows; g.N = K; g.K = e->out_ld[l];          // (k runs over the padded output width: zero pad columns of dA)
         g.ldc = K; g.split_k = 1;
         if (to_dx) {
             g.C = dx_f32; g.c_f32 = 1;
         } else {
-            g.C = dact_ptr(e, b, l - 1); g.c_f32 = 0;
-            if (e->relu[l - 1]) { g.relu_src = reinterpret_cast<const bf16_t*>(act_ptr(e, b, l)); g.ld_relu = K; }
+            g.C = dact_ptr(e, b, l - 1); g.c_f32 = 0; g.ldc = e->out_ld[l - 1];
+            if (e->relu[l - 1]) { g.relu_src = reinterpret_cast<const bf16_t*>(act_ptr(e, b, l)); g.ld_relu = e->in_ld[l]; }
             g.colsum_part = part_ptr(e, b, l - 1);
             e->parts_pending[l - 1] = gemm_bf16_colsum_rows(g);
             if (b->shadow_wt != nullptr && l >= 2 && !e->cfg.no_wt && !e->cfg.no_prefetch) {      // the next data gradient's operand
@@ -673,9 +678,10 @@ int codae_create(const codae_spec* spec, codae_handle* out) {
         CODAE_REQUIRE(l == 0 || spec->in_features[l] == spec->out_features[l - 1],
                       "codae_create: layer %d input %d != previous output %d", l, spec->in_features[l], spec->out_features[l - 1]);
         if (spec->precision == CODAE_PREC_BF16) {
-            // every width is both a GEMM k extent (whole 64-deep tiles) and an n extent
-            if (spec->in_features[l] % 64 != 0 || spec->out_features[l] % 64 != 0) {
-                set_error("codae_create: bf16 mode needs every layer width to be a multiple of 64 (layer %d is %d -> %d); use CODAE_PREC_F32",
+            // 16-byte rows (8 bf16) everywhere: vector loads / stores of the gather, the epilogues and the k-strided staging.  (Round 2
+            // needed multiples of 64: every width is also a GEMM k extent; the activation buffers now carry that padding themselves.)
+            if (spec->in_features[l] % 8 != 0 || spec->out_features[l] % 8 != 0) {
+                set_error("codae_create: bf16 mode needs every layer width to be a multiple of 8 (layer %d is %d -> %d); use CODAE_PREC_F32",
                           l, spec->in_features[l], spec->out_features[l]);
                 return CODAE_E_UNSUPPORTED;
             }
@@ -693,10 +699,12 @@ int codae_create(const codae_spec* spec, codae_handle* out) {
         e->in.push_back(spec->in_features[l]);
         e->out.push_back(spec->out_features[l]);
         e->relu.push_back(spec->relu[l] ? 1 : 0);
+        e->in_ld.push_back(e->prec == CODAE_PREC_BF16 ? (int)round_up(e->in[l], 64) : e->in[l]);
+        e->out_ld.push_back(e->prec == CODAE_PREC_BF16 ? (int)round_up(e->out[l], 64) : e->out[l]);
         e->w_off.push_back(off);
         off += round_up((int64_t)e->in[l] * e->out[l], 64);
-        if (e->in[l] > e->maxw) e->maxw = e->in[l];
-        if (e->out[l] > e->maxw) e->maxw = e->out[l];
+        if (e->in_ld[l] > e->maxw) e->maxw = e->in_ld[l];
+        if (e->out_ld[l] > e->maxw) e->maxw = e->out_ld[l];
     }
     e->bias_begin = off;
     for (int l = 0; l < e->L; ++l) {
@@ -707,7 +715,7 @@ int codae_create(const codae_spec* spec, codae_handle* out) {
     int64_t a = 0;
     for (int l = 0; l < e->L; ++l) {
         e->act_off.push_back(a);
-        a += round_up((int64_t)e->max_rows * e->in[l] * e->esize(), 256);
+        a += round_up((int64_t)e->max_rows * e->in_ld[l] * e->esize(), 256);
     }
     e->act_off.push_back(a);  // y, always fp32
     a += round_up((int64_t)e->max_rows * e->out[e->L - 1] * 4, 256);
@@ -717,6 +725,16 @@ int codae_create(const codae_spec* spec, codae_handle* out) {
     // two backward streams, whose barrier packets cost ~11 us each); deeper stacks rotate through CODAE_MAX_DACT
     e->n_dact = e->L + 1 <= CODAE_MAX_DACT ? e->L + 1 : CODAE_MAX_DACT;
     if (e->n_dact < 3) e->n_dact = 3;
+    if (e->prec == CODAE_PREC_BF16 && e->n_dact <= e->L) {
+        // rotating buffers are shared by layers of different widths: one layer's zero pad columns would be another's data
+        for (int l = 0; l < e->L; ++l)
+            if (e->in[l] % 64 != 0 || e->out[l] % 64 != 0) {
+                set_error("codae_create: bf16 stacks deeper than %d layers need widths that are multiples of 64 (layer %d is %d -> %d)",
+                          CODAE_MAX_DACT - 1, l, e->in[l], e->out[l]);
+                delete e;
+                return CODAE_E_UNSUPPORTED;
+            }
+    }
     e->chain_ok = e->prec == CODAE_PREC_BF16 && !e->cfg.no_chain && e->L + 1 <= CODAE_MAX_DACT &&
                   chain_supported(e->L, e->in.data(), e->out.data()) && e->in[0] == e->out[e->L - 1];
     // partial column-sum rows per layer: a producer writes at most one row per 64 batch rows (exact-fp32 GEMM, dense
@@ -818,7 +836,9 @@ int codae_profile_end(codae_handle h, int32_t* kinds, float* ms, int32_t capacit
 int codae_get_sizes(codae_handle h, codae_sizes* out) {
     CODAE_REQUIRE(h && out, "codae_get_sizes: null argument");
     out->n_param = h->n_param;
-    out->n_weight = h->prec == CODAE_PREC_BF16 ? h->n_param : 0;
+    // (+ 64 rows of slack behind the last matrix: a GEMM whose k extent is a padded width reads the weight operand up to 63
+    //  elements / rows past a row's / the matrix's end - multiplied by the zero pad columns of the activations, see in_ld)
+    out->n_weight = h->prec == CODAE_PREC_BF16 ? h->n_param + (int64_t)64 * h->maxw : 0;
     out->act_bytes = h->act_bytes;
     out->dact_bytes = h->n_dact * h->dact_one;
     out->slab_bytes = 3 * h->slab_bytes;   // side stream: two alternating slab buffers; caller's stream (tail wgrad): the third
@@ -856,9 +876,9 @@ int codae_forward(codae_handle h, const codae_buffers* b, const float* x, float*
     // ingest x into act[layer_lo] in working precision (no gather, no mask)
     codae_batch in{};
     in.data = x; in.B = B; in.io = h->in[layer_lo];
-    rc = launch_gather_corrupt(&in, act_ptr(h, b, layer_lo), h->prec == CODAE_PREC_BF16, s);
+    rc = launch_gather_corrupt(&in, act_ptr(h, b, layer_lo), h->prec == CODAE_PREC_BF16, s, h->in_ld[layer_lo]);
     if (rc) return rc;
-    rc = zero_pad_rows(h, act_ptr(h, b, layer_lo), B, rows, h->in[layer_lo], s);
+    rc = zero_pad_rows(h, act_ptr(h, b, layer_lo), B, rows, h->in_ld[layer_lo], s);
     if (rc) return rc;
     for (int l = layer_lo; l < layer_hi; ++l) {
         const bool last = (l == layer_hi - 1);
@@ -886,9 +906,9 @@ int codae_backward(codae_handle h, const codae_buffers* b, const float* dy, floa
     // dA_top = dy in working precision; db_top = column sums of dy (per 64-row block here, added up after the chain)
     codae_batch in{};
     in.data = dy; in.B = B; in.io = h->out[top];
-    rc = launch_gather_corrupt(&in, dact_ptr(h, b, top), h->prec == CODAE_PREC_BF16, s);
+    rc = launch_gather_corrupt(&in, dact_ptr(h, b, top), h->prec == CODAE_PREC_BF16, s, h->out_ld[top]);
     if (rc) return rc;
-    rc = zero_pad_rows(h, dact_ptr(h, b, top), B, rows, h->out[top], s);
+    rc = zero_pad_rows(h, dact_ptr(h, b, top), B, rows, h->out_ld[top], s);
     if (rc) return rc;
     rc = launch_colsum_parts_f32(dy, B, h->out[top], part_ptr(h, b, top), s);
     if (rc) return rc;
@@ -912,10 +932,10 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
     const bool bf = h->prec == CODAE_PREC_BF16;
     {
         ProfScope prof(h, CODAE_K_GATHER, s);
-        rc = launch_gather_corrupt(batch, act_ptr(h, b, 0), bf, s);
+        rc = launch_gather_corrupt(batch, act_ptr(h, b, 0), bf, s, h->in_ld[0]);
     }
     if (rc) return rc;
-    rc = zero_pad_rows(h, act_ptr(h, b, 0), B, rows, h->in[0], s);
+    rc = zero_pad_rows(h, act_ptr(h, b, 0), B, rows, h->in_ld[0], s);
     if (rc) return rc;
     float* y = out_y ? out_y : reinterpret_cast<float*>(act_ptr(h, b, L));
     // bf16 training step: the loss is folded into the last forward GEMM's epilogue (y never stored)
@@ -927,10 +947,10 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
             fwd_group.close();
             const double n_glob = (double)(hyper->loss_scale_rows > 0.f ? hyper->loss_scale_rows : (float)B) * batch->io;
             GemmBf16 g{};
-            g.A = reinterpret_cast<const bf16_t*>(act_ptr(h, b, l)); g.lda = h->in[l]; g.a_mode = OP_KC;
+            g.A = reinterpret_cast<const bf16_t*>(act_ptr(h, b, l)); g.lda = h->in_ld[l]; g.a_mode = OP_KC;
             g.B = reinterpret_cast<const bf16_t*>(b->shadow_w) + h->w_off[l]; g.ldb = h->in[l]; g.b_mode = OP_KC;
-            g.C = dact_ptr(h, b, l); g.ldc = h->out[l]; g.c_f32 = 0;
-            g.M = rows; g.N = h->out[l]; g.K = h->in[l];
+            g.C = dact_ptr(h, b, l); g.ldc = h->out_ld[l]; g.c_f32 = 0;
+            g.M = rows; g.N = h->out[l]; g.K = h->in_ld[l];
             g.bias = b->params + h->b_off[l]; g.relu = 0; g.split_k = 1;
             g.colsum_part = part_ptr(h, b, l);
             g.loss.enabled = 1; g.loss.data = batch->data; g.loss.row_idx = batch->row_idx; g.loss.mask_id = batch->mask_id;
@@ -960,12 +980,12 @@ int codae_step_forward_loss(codae_handle h, const codae_buffers* b, const codae_
     fwd_group.close();
     if (hyper != nullptr) {
         const double n_glob = (double)(hyper->loss_scale_rows > 0.f ? hyper->loss_scale_rows : (float)B) * batch->io;
-        rc = zero_pad_rows(h, dact_ptr(h, b, L - 1), B, rows, batch->io, s);
+        rc = zero_pad_rows(h, dact_ptr(h, b, L - 1), B, rows, h->out_ld[L - 1], s);
         if (rc) return rc;
         {
             ProfScope prof(h, CODAE_K_LOSS, s);
             rc = launch_mse_loss(batch, y, dact_ptr(h, b, L - 1), bf, (float)(1.0 / n_glob), part_ptr(h, b, L - 1),
-                                 loss_parts_ptr(h, b), 1, s);
+                                 loss_parts_ptr(h, b), 1, s, h->out_ld[L - 1]);
         }
         if (rc) return rc;
         h->parts_pending[L - 1] = mse_loss_colsum_rows(B);

@@ -198,6 +198,38 @@ def test_fused_bf16_matches_bf16_rounded_oracle(name, step_path):
                 assert _rel_l2(eng.bias_grad(l).cpu().numpy(), gb) <= 2e-3, ("db", l)
 
 
+@pytest.mark.parametrize("name", ["embedding_square", "embedding_taper"])
+def test_fused_bf16_on_widths_that_are_not_multiples_of_64(name):
+    """The reference only requires io % embedding_size == 0; its stock fixtures here are 3 x 16 = 48 wide (square) and taper
+    48 -> 40 -> 32 -> 24 -> 16 -> ... -> 48.  Round 2's bf16 engine refused such stacks (every width is a GEMM k extent of whole
+    64-deep tiles) and they fell to the exact-fp32 engine; now the activation / activation-gradient buffers carry zero pad columns
+    up to the next multiple of 64 and the weights stay unpadded (a row's over-read is the head of the next row, times zero).
+    The reference run's first epoch through the bf16 step against the bf16-rounding oracle: first-step loss 1e-6, every gradient
+    tensor to 2e-3 relative L2 (the kernel-level bound of the wide fixtures), later steps loss 4e-4 / grad-norm 1e-2."""
+    from oracle import dae_oracle as O
+    g = Golden(name)
+    m = g.meta
+    ad = FusedTrainerAdapter(g, "bf16")
+    eng = ad.t.engine
+    assert eng.precision == 1 and any(k % 64 or n % 64 for k, n, _ in eng.schedule)
+    orc = O.EmbeddingTrainer(g.params("init"), g.relu_flags(), m["lr"], m["weight_decay"], quant=O.bf16_round)
+    n_train = sum(1 for _ in g.calls()[:6])
+    for step, (idx, run) in enumerate(g.calls()[:n_train]):
+        _, fmask = O.get_masks(g["binary_masks"], g["nb_missing_per_run"], g["mask_to_use"], 1, idx, run)
+        ro = orc.step(g["data"][idx], fmask)
+        eng.zero_metric_sums()
+        ad.t.train_batch(torch.tensor(idx, dtype=torch.int32, device=DEV), run=run)
+        sq, sqp, gsq, loss = eng.read_scalars()
+        first = step == 0
+        assert abs(loss - float(ro["loss"])) <= (1e-6 if first else 4e-4) * float(ro["loss"]), (step, loss, ro["loss"])
+        assert abs(math.sqrt(gsq) - float(ro["grad_norm"])) <= (1e-5 if first else 1e-2) * float(ro["grad_norm"]), (step, math.sqrt(gsq), ro["grad_norm"])
+        assert abs(sqp - float(ro["sq_partial"])) <= (1e-6 if first else 6e-4) * float(ro["sq_partial"])
+        if first:
+            for l, (gw, gb) in enumerate(orc.last_grads):
+                assert _rel_l2(eng.weight_grad(l).cpu().numpy(), gw) <= 2e-3, ("dW", l)
+                assert _rel_l2(eng.bias_grad(l).cpu().numpy(), gb) <= 2e-3, ("db", l)
+
+
 @pytest.mark.parametrize("name", ["embedding_wide_square", "embedding_wide_taper"])
 def test_fused_first_step_grads_bf16(name):
     g = Golden(name)
@@ -445,7 +477,8 @@ def test_engine_rejects_bad_shapes():
     from codae.hip import HipError
     from codae.hip.engine import DaeEngine
     with pytest.raises(HipError):
-        DaeEngine([(11, 11, True), (11, 11, False)], 64, "bf16", DEV)      # widths not % 64
+        DaeEngine([(11, 11, True), (11, 11, False)], 64, "bf16", DEV)      # widths not % 8 (16-byte rows)
+    DaeEngine([(48, 40, True), (40, 48, False)], 64, "bf16", DEV)          # not % 64: fine since round 3 (padded row strides)
     eng = DaeEngine([(11, 11, True), (11, 11, False)], 64, "f32", DEV)
     with pytest.raises(HipError):
         eng.forward(torch.zeros(65, 11, device=DEV))                         # batch > max_batch
@@ -1016,6 +1049,10 @@ def _fuzz_cases():
         z = int(rng.choice([io, max(64, (io // 2) // 64 * 64), 64]))
         B = int(rng.integers(65, 2600))
         cases.append((S, E, z, int(rng.integers(2, 5)), int(rng.integers(2, 5)), B))   # (1 layer per side: the reference itself raises)
+    # widths that are multiples of 8 but not of 64 (the reference only asks io % embedding_size == 0): bf16 engine on padded row
+    # strides; and one that is not a multiple of 8 (exact-fp32 engine)
+    cases += [(3, 16, 48, 2, 2, 200), (3, 24, 40, 3, 2, 777), (5, 40, 104, 2, 3, 1500), (4, 72, 136, 4, 4, 2200), (3, 168, 504, 2, 2, 1111),
+              (3, 20, 30, 2, 2, 300)]
     return cases
 
 
@@ -1023,14 +1060,14 @@ def _fuzz_cases():
 def test_fused_random_topologies_vs_oracle(S, E, z, nb_in, nb_out, B, step_path):
     """Seeded random stacks (tapers to z, 2-4 hidden layers per side, ragged batches, every tile / split-K choice
     the dispatcher makes for them): two fused steps against the fp32 oracle - bf16 kernels when every width is a multiple
-    of 64 (loss within 2 %, grad-norm 10 %), exact-fp32 kernels otherwise (1e-3 / 5e-3)."""
+    of 8 (loss within 2 %, grad-norm 10 %), exact-fp32 kernels otherwise (1e-3 / 5e-3)."""
     from codae.train import HipEmbeddingTrainer
     from oracle import dae_oracle as O
     io = S * E
     rng = np.random.default_rng(S * 1000 + E + B)
     sched = O.layer_schedule(io, z, nb_in, nb_out, False, "embedding")
-    # widths that are not multiples of 64 exist only in the exact-fp32 mode (any shape): tighter tolerance there
-    precision = "f32" if any(k % 64 or n % 64 for k, n, _ in sched) else "bf16"
+    # widths that are not multiples of 8 (16-byte bf16 rows) exist only in the exact-fp32 mode (any shape): tighter tolerance there
+    precision = "f32" if any(k % 8 or n % 8 for k, n, _ in sched) else "bf16"
     tol = 1e-3 if precision == "f32" else 2e-2
     N = 2 * B
     data = rng.random((N, io), dtype=np.float32)
