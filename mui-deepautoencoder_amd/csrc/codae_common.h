@@ -93,7 +93,6 @@ struct EnvToggles {
     bool no_wt = false, single_stream = false, tail_on_side = false, no_fused_loss = false, flat_adam = false,
          no_fused_norm = false, no_chain = false, no_deep_small = false,      // CODAE_NO_DEEP_SMALL: 2-stage small GEMMs
          no_prefetch = false,         // CODAE_NO_PREFETCH: no touch of the next launch's weights under the epilogue
-         force_defer_wgrad = false,   // CODAE_DEFER_WGRAD: the grouped weight-gradient launch even when one layer alone fills the chip
          no_defer_wgrad = false;      // CODAE_NO_DEFER_WGRAD: per-layer split-K weight gradients beside the data-gradient chain (round 2's backward)
 };
 const EnvToggles& env();

@@ -42,7 +42,6 @@ void env_reload() {
     e.no_deep_small = getenv("CODAE_NO_DEEP_SMALL") != nullptr;
     e.no_defer_wgrad = getenv("CODAE_NO_DEFER_WGRAD") != nullptr;
     e.no_prefetch = getenv("CODAE_NO_PREFETCH") != nullptr;
-    e.force_defer_wgrad = getenv("CODAE_DEFER_WGRAD") != nullptr;
     if (const char* k = getenv("CODAE_SMALL_TILE_MAX")) e.small_tile_max = atoi(k);
     if (const char* k = getenv("CODAE_SMALL_STAGES")) e.small_stages = atoi(k) == 2 ? 2 : 4;
     g_env = e;
@@ -331,9 +330,9 @@ int run_wgrad_grouped(const codae_engine* e, const codae_buffers* b, int rows, b
 
 // Wide bf16 stack, single-GPU fused step: every layer's weight gradient in ONE launch of 256 x 192 tiles with K = the whole batch
 // (no split-K slabs, no reduce pass; sum g^2 from the epilogue), issued AFTER the data-gradient chain, which then has the chip to
-// itself.  Needs dA_l of every layer alive at once (n_dact > L).  Worth it when no single layer's weight gradient can fill the
-// chip unsplit (C3: 48 tiles per layer -> round 2 split K five ways: 47 MB of fp32 slabs written and read back per layer,
-// 0.28 ms of reduce launches per step) but all of them together can (480 tiles on 256 CUs).
+// itself.  Needs dA_l of every layer alive at once (n_dact > L) and enough tiles in total to fill the chip (C3: 48 tiles per
+// layer -> round 2 split K five ways: 47 MB of fp32 slabs written and read back per layer, 0.28 ms of reduce launches per step;
+// all ten together: 480 tiles on 256 CUs).
 bool defer_wgrad_ok(const codae_engine* e, int rows) {
     if (e->prec != CODAE_PREC_BF16 || e->cfg.no_defer_wgrad || e->cfg.single_stream || e->L > CODAE_GROUP_MAX || e->n_dact <= e->L || rows < 1024)
         return false;
@@ -344,8 +343,9 @@ bool defer_wgrad_ok(const codae_engine* e, int rows) {
         if (t > largest) largest = t;
         if ((int64_t)rows * e->out[l] * 2 >= (int64_t)1 << 32 || (int64_t)rows * e->in[l] * 2 >= (int64_t)1 << 32) return false;
     }
-    if (e->cfg.force_defer_wgrad) return total >= 200;
-    return largest < 160 && total >= 200;
+    (void)largest;      // (round 3 first kept the per-layer backward when one layer alone fills the chip - C5: 31.2 ms/step against 32.9
+                        //  grouped; with the 4 x 8 tile order of the pipelined kernel the grouped launch wins there too: 29.5 against 30.2)
+    return total >= 200;
 }
 
 int run_wgrad_deferred(const codae_engine* e, const codae_buffers* b, int rows, hipStream_t s) {

@@ -88,7 +88,17 @@ __device__ __forceinline__ void gemm_bf16_pipe_tile(const GemmBf16& g, int tiles
     }
     const int z = bid / tiles_mn;
     const int tmn = bid - z * tiles_mn;
-    const int tm = tmn / tiles_n, tn = tmn - tm * tiles_n;
+    // Tile ids walk the output in panels of TILE_GROUP_M row tiles: down the panel's rows, then on to the next column.  Any 32
+    // consecutive ids - what one XCD runs at a time - are then a 4 x 8 block of tiles sharing 4 A strips and 8 B strips in that
+    // XCD's L2, whatever the width.  (Row-major ids gave 1 x 32 at C5's 32 column tiles: every workgroup of an XCD streamed a
+    // different strip of the 75 MB weight matrix per row panel.  C3's 8 column tiles: the same 4 x 8 sets as before.)
+    constexpr int TILE_GROUP_M = 4;
+    const int tiles_m = tiles_mn / tiles_n;
+    const int grp = tmn / (TILE_GROUP_M * tiles_n);
+    const int tm0 = grp * TILE_GROUP_M;
+    const int gsz = tiles_m - tm0 < TILE_GROUP_M ? tiles_m - tm0 : TILE_GROUP_M;
+    const int within = tmn - grp * (TILE_GROUP_M * tiles_n);
+    const int tn = within / gsz, tm = tm0 + (within - tn * gsz);
     const int i0 = tm * BM, j0 = tn * BN;
     const int kt_begin = (int)((int64_t)kt_total * z / g.split_k);
     const int kt_end = (int)((int64_t)kt_total * (z + 1) / g.split_k);
