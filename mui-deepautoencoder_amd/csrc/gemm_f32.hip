@@ -92,7 +92,24 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmF32 g, bool a_vec, boo
     const int lane = t & 63, w = t >> 6;
     const int wr = w >> 1, wc = w & 1;
     const int li = lane & 31, kh = lane >> 5;
-    const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+    // XCD-aware tile map (as the bf16 kernels): workgroup b of the x-y grid runs on XCD b % 8; each XCD takes a contiguous
+    // eighth of the tile ids, and ids walk the output in panels of 4 row tiles (down the panel, then the next column), so the
+    // workgroups an XCD runs at a time share a few A row panels and B column panels in its L2 instead of one tile of every row.
+    int tile_m, tile_n;
+    {
+        const int tiles_n = gridDim.x, tiles_m = gridDim.y, nwg = tiles_n * tiles_m;
+        int id = blockIdx.y * tiles_n + blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+        constexpr int GROUP_M = 4;
+        const int grp = id / (GROUP_M * tiles_n);
+        const int tm0 = grp * GROUP_M;
+        const int gsz = tiles_m - tm0 < GROUP_M ? tiles_m - tm0 : GROUP_M;
+        const int within = id - grp * (GROUP_M * tiles_n);
+        tile_n = within / gsz;
+        tile_m = tm0 + (within - tile_n * gsz);
+    }
+    const int i0 = tile_m * BM, j0 = tile_n * BN;
     if (g.m_dev != nullptr) {                 // (g is this kernel's own copy of the descriptor)
         const int m = *g.m_dev;
         if (m < g.M) g.M = m;
@@ -177,7 +194,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmF32 g, bool a_vec, boo
             // one partial row per 64-row wave block: no atomics, the finish kernel adds the rows in order
             csum += __shfl_xor(csum, 32);
             // (a wave whose 64-row block lies wholly past M has no partial row: gemm_f32_colsum_rows = ceil(M / 64))
-            if (kh == 0 && j < g.N && i0 + 64 * wr < g.M) g.colsum_part[(int64_t)(2 * blockIdx.y + wr) * g.N + j] = csum;
+            if (kh == 0 && j < g.N && i0 + 64 * wr < g.M) g.colsum_part[(int64_t)(2 * tile_m + wr) * g.N + j] = csum;
         }
     }
 }
