@@ -92,6 +92,7 @@ struct EnvToggles {
     bool side_priority_set = false; int side_priority = 0;   // CODAE_SIDE_PRIORITY
     bool no_wt = false, single_stream = false, tail_on_side = false, no_fused_loss = false, flat_adam = false,
          no_fused_norm = false, no_chain = false, no_deep_small = false,      // CODAE_NO_DEEP_SMALL: 2-stage small GEMMs
+         no_relu_bits = false,        // CODAE_NO_RELU_BITS: the data gradient reads the saved activation for its ReLU mask
          no_prefetch = false,         // CODAE_NO_PREFETCH: no touch of the next launch's weights under the epilogue
          no_defer_wgrad = false;      // CODAE_NO_DEFER_WGRAD: per-layer split-K weight gradients beside the data-gradient chain (round 2's backward)
 };
@@ -154,6 +155,11 @@ struct GemmBf16 {
     int split_k;             // >1: fp32 partial slabs C + z*M*ldc, K range split evenly in BK units
     LossFuse loss;           // enabled: C receives dy (bf16), colsum_part the last bias gradient's partial sums
     int dbg;                 // timing-only ablations (CODAE_GEMM_DBG): 1 no LDS-DMA, 2 no MFMA, 4 no epilogue stores
+    // ReLU mask as one bit per element, [rows][ld_bits] bytes, bit k of byte (i, j / 8) = (stored value (i, j + k) > 0): written by a
+    // forward launch (relu_bits_out), read by the data-gradient launch INSTEAD of the saved activation (relu_bits; relu_src stays
+    // set for the kernels that do not take bits).  Pipelined kernels only: gemm_bf16_takes_relu_bits() says whether a launch
+    // of this shape will write / read them.
+    uint8_t* relu_bits_out; const uint8_t* relu_bits; int64_t ld_bits;
     const void* prefetch; int64_t prefetch_bytes;   // pipelined 256 x 192 kernel only: touched (one 4-B load per 128-B line, spread
                              // over the launch's workgroups) while the epilogue runs - the NEXT launch's weight matrix, which
                              // would otherwise come from HBM under its first K-tiles; null = nothing
@@ -161,6 +167,7 @@ struct GemmBf16 {
                              // CODAE_S_N_SLOTS clip_grad_norm_ slots (what sumsq_kernel would add in a pass of its own), or null
 };
 bool gemm_bf16_supported(int M, int N, int K);
+bool gemm_bf16_takes_relu_bits(int M, int N);    // forward-form bf16 launch of this output shape runs on a pipelined kernel
 int gemm_bf16_colsum_rows(const GemmBf16& g);   // rows of colsum_part this launch writes (= its tiles along M)
 int gemm_bf16_loss_parts(const GemmBf16& g);    // workgroups of the fused-loss launch = rows of LossFuse::parts
 int gemm_bf16(const GemmBf16& g, hipStream_t s);

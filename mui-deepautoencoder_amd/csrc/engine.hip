@@ -42,6 +42,7 @@ void env_reload() {
     e.no_deep_small = getenv("CODAE_NO_DEEP_SMALL") != nullptr;
     e.no_defer_wgrad = getenv("CODAE_NO_DEFER_WGRAD") != nullptr;
     e.no_prefetch = getenv("CODAE_NO_PREFETCH") != nullptr;
+    e.no_relu_bits = getenv("CODAE_NO_RELU_BITS") != nullptr;
     if (const char* k = getenv("CODAE_SMALL_TILE_MAX")) e.small_tile_max = atoi(k);
     if (const char* k = getenv("CODAE_SMALL_STAGES")) e.small_stages = atoi(k) == 2 ? 2 : 4;
     g_env = e;
@@ -77,6 +78,7 @@ struct codae_engine {
     int maxw = 0;
     std::vector<int64_t> act_off;  // byte offsets of act[0..L-1] and y (index L) inside bufs->acts
     int64_t act_bytes = 0, dact_one = 0, slab_bytes = 0;
+    std::vector<int64_t> bits_off;   // byte offset inside bufs->acts of the 1-bit ReLU mask of act[l] ([max_rows][in_ld[l] / 8]), or -1
     int n_dact = 3;          // rotating activation-gradient buffers: min(L + 1, CODAE_MAX_DACT)
     std::vector<int> split_k;
     // bias gradients: per layer a block of partial column-sum rows in bufs->bias_parts, filled by whichever kernel
@@ -399,6 +401,10 @@ int run_linear(const codae_engine* e, const codae_buffers* b, int l, const void*
         g.M = rows; g.N = N; g.K = e->in_ld[l];
         g.bias = b->params + e->b_off[l]; g.relu = e->relu[l];
         g.split_k = 1;
+        if (!y_f32 && l + 1 < e->L && e->bits_off[l + 1] >= 0 && e->relu[l] && y == act_ptr(e, b, l + 1) && gemm_bf16_takes_relu_bits(rows, N)) {
+            g.relu_bits_out = reinterpret_cast<uint8_t*>(b->acts) + e->bits_off[l + 1];
+            g.ld_bits = e->in_ld[l + 1] / 8;
+        }
         if (l + 1 < e->L && !e->cfg.no_prefetch) {        // the next layer's weights, touched under this launch's epilogue
             g.prefetch = reinterpret_cast<const bf16_t*>(b->shadow_w) + e->w_off[l + 1];
             g.prefetch_bytes = (int64_t)e->in[l + 1] * e->out[l + 1] * 2;
@@ -488,7 +494,14 @@ int run_dgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, fl
             g.C = dx_f32; g.c_f32 = 1;
         } else {
             g.C = dact_ptr(e, b, l - 1); g.c_f32 = 0; g.ldc = e->out_ld[l - 1];
-            if (e->relu[l - 1]) { g.relu_src = reinterpret_cast<const bf16_t*>(act_ptr(e, b, l)); g.ld_relu = e->in_ld[l]; }
+            if (e->relu[l - 1]) {
+                g.relu_src = reinterpret_cast<const bf16_t*>(act_ptr(e, b, l)); g.ld_relu = e->in_ld[l];
+                // (the forward launch that wrote act[l] had this output shape: rows x in[l]; same predicate on both sides)
+                if (e->bits_off[l] >= 0 && gemm_bf16_takes_relu_bits(rows, K)) {
+                    g.relu_bits = reinterpret_cast<const uint8_t*>(b->acts) + e->bits_off[l];
+                    g.ld_bits = e->in_ld[l] / 8;
+                }
+            }
             g.colsum_part = part_ptr(e, b, l - 1);
             e->parts_pending[l - 1] = gemm_bf16_colsum_rows(g);
             if (b->shadow_wt != nullptr && l >= 2 && !e->cfg.no_wt && !e->cfg.no_prefetch) {      // the next data gradient's operand
@@ -719,6 +732,15 @@ int codae_create(const codae_spec* spec, codae_handle* out) {
     }
     e->act_off.push_back(a);  // y, always fp32
     a += round_up((int64_t)e->max_rows * e->out[e->L - 1] * 4, 256);
+    // 1 bit per element of every activation that a ReLU produced (the data gradient reads these instead of the activation)
+    e->bits_off.assign(e->L, -1);
+    if (e->prec == CODAE_PREC_BF16 && !e->cfg.no_relu_bits) {
+        for (int l = 1; l < e->L; ++l) {
+            if (!e->relu[l - 1]) continue;
+            e->bits_off[l] = a;
+            a += round_up((int64_t)e->max_rows * (e->in_ld[l] / 8), 256);
+        }
+    }
     e->act_bytes = a;
     e->dact_one = round_up((int64_t)e->max_rows * e->maxw * e->esize(), 256);
     // one activation-gradient buffer per layer when the stack is shallow enough (no write-after-read waits between the

@@ -715,6 +715,18 @@ static bool small_tile_64(const GemmBf16& g) {
     return (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) <= env().small_tile_max;
 }
 
+// a forward-form (k-contiguous operands, bf16 out, unsplit) launch with this output shape goes to a pipelined kernel (256 x 192 or
+// 128 x 192 tiles), whose epilogues write / read the 1-bit ReLU mask; mirrors the dispatch at the end of gemm_bf16()
+bool gemm_bf16_takes_relu_bits(int M, int N) {
+    if (env().gemm_dbg) return false;
+    const int t = gemm_bf16_tile_big(M, N, 1);
+    if (t == 3 || t == 6 || t == 7) return true;
+    GemmBf16 probe{};
+    probe.M = M; probe.N = N; probe.a_mode = OP_KC; probe.b_mode = OP_KC; probe.c_f32 = 0; probe.split_k = 1;
+    if (small_tile_64(probe)) return false;
+    return !env().no_deep_small;
+}
+
 // rows of g.colsum_part the launch gemm_bf16(g) makes will write: one per tile along M of the tile it picks
 int gemm_bf16_colsum_rows(const GemmBf16& g) {
     const int t = gemm_bf16_tile_big(g.M, g.N, g.loss.enabled ? 1 : g.split_k, g.b_mode == OP_KS || g.c_f32);

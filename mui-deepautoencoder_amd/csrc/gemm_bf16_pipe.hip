@@ -532,17 +532,32 @@ __device__ __forceinline__ void gemm_bf16_pipe_tile(const GemmBf16& g, int tiles
             // longer than the forward one.
             bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
             constexpr int ITER = (BM + RL - 1) / RL;
-            const bool relu_mask = EPI != 1 && g.relu_src != nullptr;
+            // ReLU mask of the data gradient: one BIT per element when the forward launch left them (g.relu_bits: 1 byte per lane
+            // and row instead of 16 - the saved activation is 25 MB per launch at C3 and comes from HBM), else the activation
+            const bool bit_mask = EPI != 1 && g.relu_bits != nullptr;
+            const bool relu_mask = EPI != 1 && !bit_mask && g.relu_src != nullptr;
             const bf16_t* hsrc = relu_mask ? g.relu_src : g.A;                 // (no mask: any valid 16-B aligned bytes)
             const int64_t hld = relu_mask ? g.ld_relu : 0;
             const int jc = j < g.N ? j : 0;
+            const uint8_t* bsrc = bit_mask ? g.relu_bits : reinterpret_cast<const uint8_t*>(g.A);
+            const int64_t bld = bit_mask ? g.ld_bits : 0;
             uint4 hv[ITER];
+            uint8_t hb[ITER];
             if constexpr (EPI != 1) {
+                if (bit_mask) {
 #pragma unroll
-                for (int it = 0; it < ITER; ++it) {
-                    const int r = rl + it * RL;
-                    const bool ok = rl < RL && j < g.N && r < BM && i0 + r < g.M;
-                    hv[it] = *reinterpret_cast<const uint4*>(hsrc + (int64_t)(ok ? i0 + r : 0) * hld + (relu_mask ? jc : 0));
+                    for (int it = 0; it < ITER; ++it) {
+                        const int r = rl + it * RL;
+                        const bool ok = rl < RL && j < g.N && r < BM && i0 + r < g.M;
+                        hb[it] = bsrc[(int64_t)(ok ? i0 + r : 0) * bld + (ok ? (jc >> 3) : 0)];
+                    }
+                } else {
+#pragma unroll
+                    for (int it = 0; it < ITER; ++it) {
+                        const int r = rl + it * RL;
+                        const bool ok = rl < RL && j < g.N && r < BM && i0 + r < g.M;
+                        hv[it] = *reinterpret_cast<const uint4*>(hsrc + (int64_t)(ok ? i0 + r : 0) * hld + (relu_mask ? jc : 0));
+                    }
                 }
             }
 #pragma unroll
@@ -552,7 +567,13 @@ __device__ __forceinline__ void gemm_bf16_pipe_tile(const GemmBf16& g, int tiles
                 const u32x4 lv = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(smem + (ok ? r : 0) * PITCH + c * 16);
                 uint4 v = make_uint4(lv[0], lv[1], lv[2], lv[3]);
                 if constexpr (EPI != 1) {
-                    if (relu_mask) {
+                    if (bit_mask) {
+                        const uint32_t hbv = hb[it];
+                        auto keepb = [](uint32_t val, uint32_t b2) -> uint32_t {        // b2: the element pair's two mask bits
+                            return val & (((b2 & 1u) ? 0x0000ffffu : 0u) | ((b2 & 2u) ? 0xffff0000u : 0u));
+                        };
+                        v.x = keepb(v.x, hbv); v.y = keepb(v.y, hbv >> 2); v.z = keepb(v.z, hbv >> 4); v.w = keepb(v.w, hbv >> 6);
+                    } else if (relu_mask) {
                         const uint4 h = hv[it];
                         auto keep = [](uint32_t val, uint32_t hh) -> uint32_t {
                             const uint32_t lo = ((hh & 0x8000u) == 0 && (hh & 0x7fffu) != 0) ? 0x0000ffffu : 0u;
@@ -560,6 +581,26 @@ __device__ __forceinline__ void gemm_bf16_pipe_tile(const GemmBf16& g, int tiles
                             return val & (lo | hi);
                         };
                         v.x = keep(v.x, h.x); v.y = keep(v.y, h.y); v.z = keep(v.z, h.z); v.w = keep(v.w, h.w);
+                    }
+                }
+                if constexpr (EPI == 1) {
+                    if (g.relu_bits_out != nullptr) {
+                        // 1 bit per stored element: > 0 for a bf16 = sign clear and not zero - what the data gradient's `keep` tests on
+                        // the activation.  A lane's 8 elements are one byte; the 4 lanes of a quad hold 4 consecutive bytes of one
+                        // row (CH and the wave size are multiples of 4), gathered by DPP quad rotations into ONE dword store by the
+                        // quad's first lane (byte stores, 24 per row: + 1.6 us per launch; dwords: see DESIGN.md 5e).
+                        // (a ReLU output is never negative, so "> 0" = "magnitude not zero": adding 0x7fff to a 15-bit magnitude carries
+                        //  into bit 15 exactly when it is not zero - both halves of the pair at once, no compares)
+                        auto pos = [](uint32_t w2) -> uint32_t {
+                            const uint32_t t = (w2 & 0x7fff7fffu) + 0x7fff7fffu;
+                            return ((t >> 15) & 1u) | ((t >> 30) & 2u);
+                        };
+                        const uint32_t b0 = ok ? (pos(v.x) | (pos(v.y) << 2) | (pos(v.z) << 4) | (pos(v.w) << 6)) : 0u;
+                        const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b0, 0x39, 0xf, 0xf, true);      // quad_perm [1,2,3,0]
+                        const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b0, 0x4e, 0xf, 0xf, true);      // [2,3,0,1]
+                        const uint32_t b3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b0, 0x93, 0xf, 0xf, true);      // [3,0,1,2]
+                        if (ok && (c & 3) == 0)
+                            *reinterpret_cast<uint32_t*>(g.relu_bits_out + (int64_t)(i0 + r) * g.ld_bits + (j >> 3)) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
                     }
                 }
                 if (ok) {

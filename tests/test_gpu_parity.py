@@ -971,6 +971,8 @@ def test_small_and_mid_tiles_give_the_bits_of_the_128x128_kernel(monkeypatch, S,
         else:
             monkeypatch.setenv("CODAE_NO_DEEP_SMALL", "1")
         monkeypatch.setenv("CODAE_WGRAD_SPLITK", "1" if B <= 256 else "5")      # the same K split on both sides
+        monkeypatch.setenv("CODAE_NO_DEFER_WGRAD", "1")                         # (per-layer weight gradients on both sides)
+        monkeypatch.setenv("CODAE_NO_RELU_BITS", "1")      # (the workspace is compared whole: no 1-bit mask region that only one side writes)
         tr = HipEmbeddingTrainer(sched, torch.tensor(data), torch.tensor(bm).to(torch.uint8), torch.tensor(mtu), 1e-3, 1e-4, 100.0,
                                  max_batch=B, precision="bf16", device=DEV)
         tr.load_params(params)
@@ -985,6 +987,44 @@ def test_small_and_mid_tiles_give_the_bits_of_the_128x128_kernel(monkeypatch, S,
     assert torch.equal(aa, ab), "saved activations"
     assert float((ba - bb).abs().max()) <= 1e-5 * float(bb.abs().max())
     assert abs(sa[3] - sb[3]) <= 1e-6 * abs(sb[3])
+
+
+@pytest.mark.parametrize("S,E,B", [(3, 512, 3000), (3, 320, 8192), (3, 24, 1500)], ids=["mid-128x192", "big-256x192", "narrow-padded"])
+def test_one_bit_relu_mask_gives_the_bits_of_the_activation_mask(monkeypatch, S, E, B):
+    """The data gradient's ReLU mask as one bit per element, written by the forward epilogue (round 3), against the mask taken
+    from the saved activation (CODAE_NO_RELU_BITS=1): two fused steps - activation gradients, weight and bias gradients,
+    updated parameters bit-identical (the bit IS `activation > 0` of the stored bf16 value)."""
+    from codae.train import HipEmbeddingTrainer
+    from oracle import dae_oracle as O
+    io = S * E
+    rng = np.random.default_rng(B + E)
+    N = B + 64
+    data = rng.random((N, io), dtype=np.float32)
+    sched = O.layer_schedule(io, io, 3, 2, False, "embedding")
+    params = O.init_params(sched, rng)
+    bm, _, _ = O.corrupter_tables([{"size": E, "position": s * E} for s in range(S)], 1)
+    mtu = rng.integers(0, S, (N, 1)).astype(np.int32)
+    idx = torch.tensor(rng.permutation(N)[:B], dtype=torch.int32, device=DEV)
+    outs = []
+    for bits in (True, False):
+        if bits:
+            monkeypatch.delenv("CODAE_NO_RELU_BITS", raising=False)
+        else:
+            monkeypatch.setenv("CODAE_NO_RELU_BITS", "1")
+        monkeypatch.setenv("CODAE_NO_CHAIN", "1")
+        tr = HipEmbeddingTrainer(sched, torch.tensor(data), torch.tensor(bm).to(torch.uint8), torch.tensor(mtu), 1e-3, 1e-4, 1.0,
+                                 max_batch=B, precision="bf16", device=DEV)
+        tr.load_params(params)
+        for _ in range(2):
+            tr.train_batch(idx, run=0)
+        eng = tr.engine
+        outs.append((eng.dacts.clone(), eng.grads.clone(), eng.params.clone(), eng.read_scalars()))
+    (da, ga, pa, sa), (db, gb, pb, sb) = outs
+    assert float(ga.abs().max()) > 0
+    assert torch.equal(da, db), "activation gradients"
+    assert torch.equal(ga, gb), "gradients"
+    assert torch.equal(pa, pb), "parameters"
+    assert sa == sb
 
 
 @pytest.mark.parametrize("B", [128, 500])
