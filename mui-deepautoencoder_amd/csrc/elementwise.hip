@@ -483,15 +483,23 @@ __global__ __launch_bounds__(NT) void reduce_slabs_epi_kernel(const float* __res
 }
 
 // parts[block][c] = sum over the block's 64 rows of src[r][c]   (bias gradient of a dense dy, first stage)
+// grid (row blocks, column chunks of NT): 8 row loads in flight per thread, added in row order (the same bits as a plain loop:
+// that form - 128 blocks walking 64 dependent loads each - took 94 us for the 50 MB dy of the drop-in backward at C3)
 __global__ __launch_bounds__(NT) void colsum_parts_f32_kernel(const float* __restrict__ src, int M, int N,
                                                               float* __restrict__ parts) {
     const int r_begin = blockIdx.x * 64;
     const int r_end = min(M, r_begin + 64);
-    for (int c = threadIdx.x; c < N; c += NT) {
-        float s = 0.f;
-        for (int r = r_begin; r < r_end; ++r) s += src[(int64_t)r * N + c];
-        parts[(int64_t)blockIdx.x * N + c] = s;
+    const int c = blockIdx.y * NT + threadIdx.x;
+    if (c >= N) return;
+    float s = 0.f;
+    for (int r0 = r_begin; r0 < r_end; r0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = src[(int64_t)min(r0 + k, r_end - 1) * N + c];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += (r0 + k < r_end) ? v[k] : 0.f;
     }
+    parts[(int64_t)blockIdx.x * N + c] = s;
 }
 
 // out[c] = sum_r src[r][c], rows in index order, one thread per column (stand-alone primitive: small problems)
@@ -893,7 +901,7 @@ int launch_colsum_f32(const float* src, int M, int N, float* out, hipStream_t s)
 
 int launch_colsum_parts_f32(const float* src, int M, int N, float* parts, hipStream_t s) {
     CODAE_REQUIRE(src && parts && M > 0 && N > 0, "colsum_parts: bad args");
-    hipLaunchKernelGGL(colsum_parts_f32_kernel, dim3((M + 63) / 64), dim3(NT), 0, s, src, M, N, parts);
+    hipLaunchKernelGGL(colsum_parts_f32_kernel, dim3((M + 63) / 64, (N + NT - 1) / NT), dim3(NT), 0, s, src, M, N, parts);
     CODAE_LAUNCH_CHECK();
     return CODAE_OK;
 }

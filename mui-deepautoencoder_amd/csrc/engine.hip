@@ -599,7 +599,8 @@ int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi
     // (Measured and dropped: the slab reduces on the caller's stream one layer late, or on a third stream - no
     // gain, 1.83 / 1.84 vs 1.82 ms at the time; every GEMM on the caller's stream with only the reduces beside
     // them - 0.27 ms slower: each cross-queue event costs ~10 us.)
-    if (step_mode && join && lo == 0 && hi == h->L && h->L >= 2 && defer_wgrad_ok(h, rows)) {
+    // (the drop-in backward - codae_backward over the whole stack without an input gradient - takes the same schedule)
+    if ((step_mode || dx == nullptr) && join && lo == 0 && hi == h->L && h->L >= 2 && defer_wgrad_ok(h, rows)) {
         // data-gradient chain alone on the chip, then all weight gradients in one launch (see defer_wgrad_ok); one stream
         int rc = join_side(h, s);                  // (an earlier bucketed backward may have left work on the side stream)
         if (rc) return rc;
