@@ -162,7 +162,7 @@ def main():
                     help="do not record per-launch hipEvents in the timed region (roofline then null)")
     ap.add_argument("--buckets", type=int, default=0,
                     help="N > 1: gradient buckets of the all-reduce (0 = one per layer, SURVEY.md 8e: the first collective starts "
-                         "one layer into the backward and the exposed tail is one layer's 9.4 MB)")
+                         "one layer into the backward and the exposed tail is one layer's 9.4 MB; 4 with --sharded-update)")
     ap.add_argument("--sharded-update", action="store_true",
                     help="N > 1: reduce-scatter the gradient buckets, Adam on 1/N of the parameters, all-gather the bf16 shadows")
     ap.add_argument("--fwd-events-only", action="store_true", help="time only the forward GEMM class")
@@ -216,7 +216,7 @@ def main():
 
     tr = HipEmbeddingTrainer(schedule, torch.from_numpy(data), torch.from_numpy(table), mask_to_use, LR, WD, CLIP,
                              max_batch=B, precision=args.precision, device=dev, distributed=distributed,
-                             n_buckets=(args.buckets if args.buckets > 0 else len(schedule)), use_graph=args.graph and not distributed,
+                             n_buckets=(args.buckets if args.buckets > 0 else None), use_graph=args.graph and not distributed,
                              sharded_update=args.sharded_update)
     tr.init_params(seed=0)
 
