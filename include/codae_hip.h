@@ -55,7 +55,9 @@ enum {
 /* arithmetic of the GEMM chain */
 enum {
     CODAE_PREC_F32 = 0,  /* parity mode: fp32 operands, v_mfma_f32_32x32x2_f32 (exact fp32 fma chain) */
-    CODAE_PREC_BF16 = 1  /* throughput mode: bf16 operands, fp32 accumulate, v_mfma_f32_16x16x32_bf16 */
+    CODAE_PREC_BF16 = 1  /* throughput mode: bf16 operands, fp32 accumulate, v_mfma_f32_16x16x32_bf16; every layer width a
+                          * multiple of 8 (16-byte rows; the activation buffers pad their rows to multiples of 64 themselves);
+                          * codae_create returns CODAE_E_UNSUPPORTED otherwise (the caller falls back to CODAE_PREC_F32) */
 };
 
 typedef struct codae_engine* codae_handle;
@@ -235,7 +237,11 @@ int codae_sync_transposed(codae_handle h, const codae_buffers* bufs, void* strea
  * layer; weights stream from L2 through per-wave LDS rings), ONE grouped launch for every layer's weight gradient (with
  * the norm's sum g^2), bias finish + loss finish, Adam: 4 launches instead of ~55 (the reference's stock BATCH_SIZE 128
  * on a narrow stack and BASELINE config 2 are launch-bound).  Same arithmetic, same buffers; CODAE_NO_CHAIN=1 keeps
- * the per-layer path; codae_step_path tells which one a batch size takes. */
+ * the per-layer path; codae_step_path tells which one a batch size takes.
+ * Wide stacks (per-layer path, batch >= 1024 rows, at most 15 layers, >= 200 tiles of 256 x 192 over all weight gradients): the
+ * backward is the data-gradient chain followed by ONE grouped launch for every layer's weight gradient with the whole batch as
+ * its k extent - no split-K slabs, no reduce pass (CODAE_NO_DEFER_WGRAD=1: the per-layer weight gradients of
+ * codae_step_backward, which data-parallel callers use bucket by bucket). */
 int codae_train_step(codae_handle h, const codae_buffers* bufs, const codae_batch* batch,
                      const codae_hyper* hyper, void* stream);
 /* 1 if codae_train_step / codae_eval_step with B rows run the persistent chain on this engine and these buffers, 0 if the
@@ -250,7 +256,8 @@ int codae_eval_step(codae_handle h, const codae_buffers* bufs, const codae_batch
 enum {
     CODAE_K_GEMM_FWD = 0,   /* y = act(x W^T + b) */
     CODAE_K_GEMM_DGRAD = 1, /* dx = (dy W) * relu' */
-    CODAE_K_GEMM_WGRAD = 2, /* dW = dy^T x (the GEMM launch only) */
+    CODAE_K_GEMM_WGRAD = 2, /* dW = dy^T x (the GEMM launch only); the grouped launch of a wide stack's step is reported as one
+                             * record per weight gradient inside it, each with elapsed / count */
     CODAE_K_LOSS = 3,       /* MSE loss fwd+bwd; in the fused bf16 step: the last forward GEMM with the loss in its epilogue */
     CODAE_K_GATHER = 4,
     CODAE_K_SUMSQ = 5,
