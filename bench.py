@@ -165,6 +165,9 @@ def main():
                          "one layer into the backward and the exposed tail is one layer's 9.4 MB; 4 with --sharded-update)")
     ap.add_argument("--sharded-update", action="store_true",
                     help="N > 1: reduce-scatter the gradient buckets, Adam on 1/N of the parameters, all-gather the bf16 shadows")
+    ap.add_argument("--native-rccl", action="store_true",
+                    help="N > 1: the library's own RCCL communicator issues the bucket all-reduces inside one call per step "
+                         "(codae_train_step_dp; opt-in: only ever run with one rank on this build's test boxes)")
     ap.add_argument("--fwd-events-only", action="store_true", help="time only the forward GEMM class")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (single GPU; no live kernel events)")
     args = ap.parse_args()
@@ -217,7 +220,7 @@ def main():
     tr = HipEmbeddingTrainer(schedule, torch.from_numpy(data), torch.from_numpy(table), mask_to_use, LR, WD, CLIP,
                              max_batch=B, precision=args.precision, device=dev, distributed=distributed,
                              n_buckets=(args.buckets if args.buckets > 0 else None), use_graph=args.graph and not distributed,
-                             sharded_update=args.sharded_update)
+                             sharded_update=args.sharded_update, native_dp=args.native_rccl)
     tr.init_params(seed=0)
 
     # per-step row indices, resident before timing: one permutation of the dataset per epoch, the
@@ -333,7 +336,7 @@ def main():
     if distributed:
         dp_info = {"rccl_ranks": int(dist.get_world_size()), "backend": dist.get_backend(),
                    "buckets": [list(b) for b in tr.dp.buckets], "exposed_wait_ms_per_step": tr.dp.wait_report(),
-                   "sharded_update": bool(tr.dp.sharded)}
+                   "sharded_update": bool(tr.dp.sharded), "native_rccl": bool(tr.dp.native)}
 
     # exact-fp32 (parity) mode on the same workload: the mode every reference-pinned rtol 1e-3 / atol 1e-5 replay runs in
     f32_parity = None

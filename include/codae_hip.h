@@ -40,7 +40,7 @@ extern "C" {
  *      codae_step_update_span, codae_sync_transposed, codae_dgrad_bf16's partial-sum workspace
  *   4: + codae_ranking_loss_batched, codae_gather_inventory_rows, codae_step_path (new entries only; no layout change)
  *   5: + codae_monitor_accumulate; codae_ranking_loss_batched takes val_group (rows of the validation inventory that are
- *      exact duplicates of each other) behind val_pos
+ *      exact duplicates of each other) behind val_pos; + codae_dp_unique_id / _init / _destroy, codae_train_step_dp
  * The binding must refuse a library whose codae_abi_version() differs and must check its own struct sizes against
  * codae_struct_sizes() at load (mui-deepautoencoder_amd/codae/hip/__init__.py does both). */
 #define CODAE_ABI_VERSION 5
@@ -244,6 +244,21 @@ int codae_sync_transposed(codae_handle h, const codae_buffers* bufs, void* strea
  * codae_step_backward, which data-parallel callers use bucket by bucket). */
 int codae_train_step(codae_handle h, const codae_buffers* bufs, const codae_batch* batch,
                      const codae_hyper* hyper, void* stream);
+/* ---- data parallel with a library-owned RCCL communicator (one process per GPU) ----------------------------
+ * RCCL is dlopen()ed on first use (the copy already in the process, else the system's): the library does not link it.
+ * codae_dp_unique_id: rank 0 fills `out` (capacity >= 128 bytes) with an ncclUniqueId and ships it to the other ranks by any
+ * means; codae_dp_init (collective: every rank calls it with the same id) creates this engine's communicator and its
+ * highest-priority collective stream; codae_destroy / codae_dp_destroy release them. */
+int codae_dp_unique_id(void* out, int32_t capacity);
+int codae_dp_init(codae_handle h, const void* unique_id, int32_t rank, int32_t world);
+int codae_dp_destroy(codae_handle h);
+/* One data-parallel optimizer step with the collectives inside the call: forward + loss, the backward in n_buckets layer
+ * ranges [bucket_lo[i], bucket_hi[i]) from the top layer down to layer 0, each range's weight gradients all-reduced (SUM, in
+ * place, fp32) on the communicator's stream as soon as they exist - no host round trip between buckets -, the bias block
+ * last, ONE wait of `stream` for the collectives, then clip + Adam on the summed gradients.  hyper->loss_scale_rows = the
+ * GLOBAL batch rows.  (What DistributedDataParallel's bucket hooks + optimizer.step do around script/train_dae_on_embedding.py:210-215.) */
+int codae_train_step_dp(codae_handle h, const codae_buffers* bufs, const codae_batch* batch, const codae_hyper* hyper,
+                        int32_t n_buckets, const int32_t* bucket_lo, const int32_t* bucket_hi, void* stream);
 /* 1 if codae_train_step / codae_eval_step with B rows run the persistent chain on this engine and these buffers, 0 if the
  * per-layer launches (tests and bench lines name the path they measured) */
 int codae_step_path(codae_handle h, const codae_buffers* bufs, int32_t B);

@@ -100,6 +100,10 @@ PROTOTYPES = {
     "codae_ranking_loss": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _I64, _P, _I32, _P, _P]),
     "codae_ranking_loss_batched": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _I32, _I32, _P, _P, _P, _I64, _P, _P, _P, _P, _I32, _P,
                                              _I32, _P, _P, _P, _P, _P]),
+    "codae_dp_unique_id": (C.c_int, [_P, _I32]),
+    "codae_dp_init": (C.c_int, [_P, _P, _I32, _I32]),
+    "codae_dp_destroy": (C.c_int, [_P]),
+    "codae_train_step_dp": (C.c_int, [_P, C.POINTER(Buffers), C.POINTER(Batch), C.POINTER(Hyper), _I32, _P, _P, _P]),
     "codae_monitor_accumulate": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P]),
     "codae_gather_inventory_rows": (C.c_int, [_P, _I64, _I32, _I32, _P, _I32, _P, _P]),
     "codae_step_path": (C.c_int, [_P, _P, _I32]),

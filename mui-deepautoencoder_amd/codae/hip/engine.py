@@ -189,6 +189,29 @@ class DaeEngine:
             check(fn(self._h, C.byref(self.bufs), C.byref(batch), C.byref(hyper), current_stream()))
         self.step_count += 1
 
+    # ---- data parallel with the library's own RCCL communicator (codae_dp_*) ----------------------------------------
+    def dp_unique_id(self):
+        """bytes of a fresh ncclUniqueId (call on rank 0, ship to the other ranks)."""
+        buf = (C.c_char * 128)()
+        check(self._lib.codae_dp_unique_id(buf, 128))
+        return bytes(buf)
+
+    def dp_init(self, unique_id, rank, world):
+        """Collective: every rank calls it with rank 0's id.  Creates this engine's communicator and collective stream."""
+        buf = (C.c_char * 128).from_buffer_copy(unique_id)
+        with torch.cuda.device(self.device):
+            check(self._lib.codae_dp_init(self._h, buf, int(rank), int(world)))
+
+    def train_step_dp(self, batch, hyper, buckets):
+        """codae_train_step_dp: forward + loss, bucketed backward with the all-reduces issued by the library on its own stream,
+        clip + Adam - one call, no Python between the buckets."""
+        n = len(buckets)
+        lo = (C.c_int32 * n)(*[int(a) for a, _ in buckets])
+        hi = (C.c_int32 * n)(*[int(b) for _, b in buckets])
+        with torch.cuda.device(self.device):
+            check(self._lib.codae_train_step_dp(self._h, C.byref(self.bufs), C.byref(batch), C.byref(hyper), n, lo, hi, current_stream()))
+        self.step_count += 1
+
     def step_forward_loss(self, batch, hyper, out_y=None):
         with torch.cuda.device(self.device):
             check(self._lib.codae_step_forward_loss(self._h, C.byref(self.bufs), C.byref(batch), C.byref(hyper),

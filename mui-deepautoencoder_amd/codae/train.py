@@ -116,7 +116,7 @@ class DataParallel:
     step_forward_loss(batch, hyper), step_backward(B, lo, hi), step_update(hyper).
     """
 
-    def __init__(self, engine, process_group=None, n_buckets=None, sharded=False):
+    def __init__(self, engine, process_group=None, n_buckets=None, sharded=False, native=False):
         """n_buckets: 1 .. engine.L; None = one bucket per layer (the first collective starts one layer into the
         backward, the exposed tail is one layer's gradient); sharded: see the module docstring."""
         if n_buckets is None:
@@ -131,6 +131,21 @@ class DataParallel:
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.buckets = default_buckets(engine.L, n_buckets)
         self.sharded = bool(sharded)
+        # native: the library owns the RCCL communicator (codae_dp_init) and issues the bucket all-reduces itself, on its own
+        # stream, inside ONE call per step (codae_train_step_dp) - no Python between the buckets.  torch.distributed is then
+        # used only to ship rank 0's ncclUniqueId and for the per-epoch scalar reductions.  Opt-in (CODAE_DP_NATIVE=1 / native=
+        # True): it has only ever run with one rank on this build's single-GPU test boxes.
+        import os as _os
+        self.native = bool(native) or _os.environ.get("CODAE_DP_NATIVE") == "1"
+        if self.native:
+            if self.sharded:
+                raise ValueError("native RCCL data parallel: the sharded update goes through torch.distributed only")
+            if not hasattr(engine, "dp_init"):
+                raise ValueError("native RCCL data parallel needs the HIP engine")
+            ids = [engine.dp_unique_id() if self.rank == 0 else None]
+            if dist.is_initialized() and self.world > 1:
+                dist.broadcast_object_list(ids, src=0, group=process_group)
+            engine.dp_init(ids[0], self.rank, self.world)
         if self.sharded:
             for lo, hi in self.buckets:
                 n = self._weight_span_bounds(lo, hi)
@@ -226,6 +241,9 @@ class DataParallel:
     def train_step(self, batch, hyper, B):
         """forward+loss -> bucketed backward with overlapped all-reduce -> clip+Adam.
         `hyper.loss_scale_rows` must hold the GLOBAL batch rows."""
+        if self.native:
+            self.engine.train_step_dp(batch, hyper, self.buckets)
+            return
         self.engine.step_forward_loss(batch, hyper)
         if self.sharded and (self.world > 1 or self.always_reduce):
             self._backward_reduce_scatter(B)
@@ -323,7 +341,7 @@ class HipEmbeddingTrainer:
 
     def __init__(self, schedule, data, mask_table_u8, mask_to_use_i32, lr, weight_decay, clip=1.0,
                  max_batch=8192, precision="bf16", device="cuda:0", distributed=False, n_buckets=None, use_graph=False,
-                 sharded_update=False):
+                 sharded_update=False, native_dp=False):
         """use_graph: replay the fused step from a hipGraph (codae_train_step_graph): for launch-bound shapes
         (small batches); single process only - the bucketed data-parallel step is not captured."""
         from .hip.engine import DaeEngine
@@ -333,7 +351,7 @@ class HipEmbeddingTrainer:
         self.mask_table = None if mask_table_u8 is None else mask_table_u8.to(self.device).contiguous()
         self.mask_to_use = None if mask_to_use_i32 is None else mask_to_use_i32.to(self.device).contiguous()
         self.lr, self.weight_decay, self.clip = lr, weight_decay, clip
-        self.dp = DataParallel(self.engine, n_buckets=n_buckets, sharded=sharded_update) if distributed else None
+        self.dp = DataParallel(self.engine, n_buckets=n_buckets, sharded=sharded_update, native=native_dp) if distributed else None
         self.world = self.dp.world if self.dp else 1
         self.use_graph = bool(use_graph) and self.dp is None
         # graph replay freezes kernel arguments: the step's row indices / mask ids are copied into these

@@ -8,6 +8,8 @@
 
 #include "codae_common.h"
 #include <cstring>
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library is dlopen()ed (codae_dp_init), libcodae_hip.so does not link it
 
 namespace codae {
 
@@ -115,8 +117,68 @@ struct codae_engine {
     mutable std::vector<int> prof_count;    // launches covered by the record (a GroupScope spans several)
     mutable bool prof_group = false;        // inside a GroupScope of the forward class: no per-launch pairs
     EnvToggles cfg;                         // the CODAE_* toggles as they stood at codae_create
+    struct DpState* dp = nullptr;           // data parallel with a library-owned RCCL communicator (codae_dp_init), else null
     int esize() const { return prec == CODAE_PREC_BF16 ? 2 : 4; }
     int rows_for(int B) const { return prec == CODAE_PREC_BF16 ? (int)round_up(B, 64) : B; }
+};
+
+// ---- library-owned RCCL communicator ("the library owns ... (DP) the ncclComm_t") -------------------------
+// RCCL is resolved at run time - the copy torch already loaded when there is one (soname librccl.so.1), else the system's - so
+// that libcodae_hip.so loads on a box without it and a process never holds two RCCLs.
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+
+static int rccl_load() {
+    if (g_rccl.lib != nullptr) return CODAE_OK;
+    void* lib = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+        lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);            // already in the process (torch's)
+        if (lib != nullptr) break;
+    }
+    if (lib == nullptr)
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib != nullptr) break;
+        }
+    if (lib == nullptr) { codae::set_error("codae_dp: librccl.so not found (%s)", dlerror()); return CODAE_E_UNSUPPORTED; }
+    RcclApi a;
+    a.lib = lib;
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(lib, "ncclAllReduce"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.GetErrorString) {
+        codae::set_error("codae_dp: librccl.so lacks an entry point");
+        return CODAE_E_UNSUPPORTED;
+    }
+    g_rccl = a;
+    return CODAE_OK;
+}
+
+#define CODAE_RCCL_CHECK(expr)                                                                         \
+    do {                                                                                               \
+        ncclResult_t r_ = (expr);                                                                      \
+        if (r_ != ncclSuccess) {                                                                       \
+            codae::set_error("%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
+            return CODAE_E_HIP;                                                                        \
+        }                                                                                              \
+    } while (0)
+
+constexpr int CODAE_DP_MAX_BUCKETS = 64;
+struct DpState {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    hipStream_t stream = nullptr;                       // the collectives' own stream (highest priority: its own queue pool)
+    hipEvent_t ev_bucket[CODAE_DP_MAX_BUCKETS + 1] = {};   // bucket i's gradients complete (+ the bias block)
+    hipEvent_t ev_done = nullptr;                       // every collective of the step complete
 };
 
 namespace {
@@ -820,6 +882,7 @@ int codae_destroy(codae_handle h) {
         for (int i = 0; i < CODAE_MAX_DACT; ++i) (void)hipEventDestroy(h->ev_w[i]);
         (void)hipStreamDestroy(h->side);
     }
+    if (h && h->dp) (void)codae_dp_destroy(h);
     delete h;
     return CODAE_OK;
 }
@@ -1233,6 +1296,100 @@ int codae_train_step_graph(codae_handle h, const codae_buffers* b, const codae_b
     if (rc) return rc;
     CODAE_HIP_CHECK(hipGraphLaunch(h->graph_exec, s));
     return CODAE_OK;
+}
+
+// ---- data parallel with a library-owned RCCL communicator --------------------------------
+
+int codae_dp_unique_id(void* out, int32_t capacity) {
+    CODAE_REQUIRE(out != nullptr && capacity >= (int32_t)sizeof(ncclUniqueId), "codae_dp_unique_id: need %d bytes", (int)sizeof(ncclUniqueId));
+    int rc = rccl_load();
+    if (rc) return rc;
+    ncclUniqueId id;
+    CODAE_RCCL_CHECK(g_rccl.GetUniqueId(&id));
+    memcpy(out, &id, sizeof(id));
+    return CODAE_OK;
+}
+
+int codae_dp_init(codae_handle h, const void* unique_id, int32_t rank, int32_t world) {
+    CODAE_REQUIRE(h != nullptr && unique_id != nullptr && world >= 1 && rank >= 0 && rank < world, "codae_dp_init: bad arguments");
+    CODAE_REQUIRE(h->dp == nullptr, "codae_dp_init: this engine already has a communicator");
+    int rc = rccl_load();
+    if (rc) return rc;
+    DpState* d = new DpState();
+    d->rank = rank; d->world = world;
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    ncclResult_t r = g_rccl.CommInitRank(&d->comm, world, id, rank);          // (collective: every rank calls it)
+    if (r != ncclSuccess) { set_error("ncclCommInitRank failed: %s", g_rccl.GetErrorString(r)); delete d; return CODAE_E_HIP; }
+    int prio_least = 0, prio_greatest = 0;
+    hipError_t e1 = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (e1 == hipSuccess) e1 = hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prio_greatest);
+    for (int i = 0; i <= CODAE_DP_MAX_BUCKETS && e1 == hipSuccess; ++i) e1 = hipEventCreateWithFlags(&d->ev_bucket[i], hipEventDisableTiming);
+    if (e1 == hipSuccess) e1 = hipEventCreateWithFlags(&d->ev_done, hipEventDisableTiming);
+    if (e1 != hipSuccess) {
+        set_error("codae_dp_init: stream / event creation failed: %s", hipGetErrorString(e1));
+        (void)g_rccl.CommDestroy(d->comm);
+        delete d;
+        return CODAE_E_HIP;
+    }
+    h->dp = d;
+    return CODAE_OK;
+}
+
+int codae_dp_destroy(codae_handle h) {
+    if (h == nullptr || h->dp == nullptr) return CODAE_OK;
+    DpState* d = h->dp;
+    if (d->stream) (void)hipStreamSynchronize(d->stream);
+    if (d->comm) (void)g_rccl.CommDestroy(d->comm);
+    for (int i = 0; i <= CODAE_DP_MAX_BUCKETS; ++i) if (d->ev_bucket[i]) (void)hipEventDestroy(d->ev_bucket[i]);
+    if (d->ev_done) (void)hipEventDestroy(d->ev_done);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
+    delete d;
+    h->dp = nullptr;
+    return CODAE_OK;
+}
+
+// One data-parallel optimizer step, collectives included: forward + loss; the backward bucket by bucket (layer ranges
+// [lo_i, hi_i), top down, ending at layer 0), each bucket's weight gradients all-reduced (SUM, in place, fp32) on the
+// communicator's own stream as soon as they exist on the engine's side stream - no host round trip between buckets -; the
+// bias block last; then the caller's stream waits ONCE for the collectives and runs clip + Adam on the summed gradients.
+// hyper->loss_scale_rows must hold the GLOBAL batch rows (so that the SUM is the global-batch mean gradient).
+int codae_train_step_dp(codae_handle h, const codae_buffers* b, const codae_batch* batch, const codae_hyper* hyper, int32_t n_buckets,
+                        const int32_t* bucket_lo, const int32_t* bucket_hi, void* stream) {
+    CODAE_REQUIRE(h != nullptr && h->dp != nullptr, "codae_train_step_dp: codae_dp_init has not been called on this engine");
+    CODAE_REQUIRE(b && batch && hyper && bucket_lo && bucket_hi, "codae_train_step_dp: null argument");
+    CODAE_REQUIRE(n_buckets >= 1 && n_buckets <= CODAE_DP_MAX_BUCKETS, "codae_train_step_dp: %d buckets", n_buckets);
+    CODAE_REQUIRE(bucket_hi[0] == h->L && bucket_lo[n_buckets - 1] == 0, "codae_train_step_dp: buckets must run from the top layer down to layer 0");
+    for (int i = 0; i < n_buckets; ++i) {
+        CODAE_REQUIRE(bucket_lo[i] >= 0 && bucket_lo[i] < bucket_hi[i] && (i == 0 || bucket_hi[i] == bucket_lo[i - 1]),
+                      "codae_train_step_dp: bucket %d = [%d, %d) does not continue the one above it", i, bucket_lo[i], bucket_hi[i]);
+    }
+    DpState* d = h->dp;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = codae_step_forward_loss(h, b, batch, hyper, nullptr, stream);
+    if (rc) return rc;
+    for (int i = 0; i < n_buckets; ++i) {
+        rc = backward_range(h, b, batch->B, bucket_lo[i], bucket_hi[i], nullptr, true, s, false);
+        if (rc) return rc;
+        // the bucket's weight gradients are complete, in order, on the side stream (or on s itself in single-stream mode)
+        hipStream_t producer = h->side != nullptr && !h->cfg.single_stream ? h->side : s;
+        CODAE_HIP_CHECK(hipEventRecord(d->ev_bucket[i], producer));
+        CODAE_HIP_CHECK(hipStreamWaitEvent(d->stream, d->ev_bucket[i], 0));
+        const int64_t lo_off = h->w_off[bucket_lo[i]];
+        const int64_t hi_off = bucket_hi[i] < h->L ? h->w_off[bucket_hi[i]] : h->bias_begin;
+        float* span = b->grads + lo_off;
+        CODAE_RCCL_CHECK(g_rccl.AllReduce(span, span, (size_t)(hi_off - lo_off), ncclFloat, ncclSum, d->comm, d->stream));
+    }
+    rc = join_side(h, s);
+    if (rc) return rc;
+    // (the last range finished every bias gradient on s)
+    CODAE_HIP_CHECK(hipEventRecord(d->ev_bucket[n_buckets], s));
+    CODAE_HIP_CHECK(hipStreamWaitEvent(d->stream, d->ev_bucket[n_buckets], 0));
+    float* bias = b->grads + h->bias_begin;
+    CODAE_RCCL_CHECK(g_rccl.AllReduce(bias, bias, (size_t)(h->n_param - h->bias_begin), ncclFloat, ncclSum, d->comm, d->stream));
+    CODAE_HIP_CHECK(hipEventRecord(d->ev_done, d->stream));
+    CODAE_HIP_CHECK(hipStreamWaitEvent(s, d->ev_done, 0));
+    return update_impl(h, b, hyper, s, false);
 }
 
 // ---- stand-alone ops --------------------------------------------------------------------

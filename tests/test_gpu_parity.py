@@ -536,6 +536,46 @@ def test_bucketed_allreduce_path_on_rccl_single_rank(monkeypatch):
         dist.destroy_process_group()
 
 
+def test_library_owned_rccl_step_equals_the_torch_distributed_step(monkeypatch):
+    """codae_train_step_dp - the library's own RCCL communicator, the bucket all-reduces issued on its own stream inside one call
+    per step - against the same bucketed step through torch.distributed (CODAE_DP_FORCE_ALLREDUCE=1), one rank (all this build's
+    boxes have): three steps at 3 x 256 / batch 2048, per-layer buckets: parameters, Adam moments, both bf16 shadows and the
+    step's scalars bit-identical (a one-rank SUM all-reduce is the identity; everything else is the same launches)."""
+    import torch.distributed as dist
+    from codae.train import HipEmbeddingTrainer, init_rccl_process_group
+    from oracle import dae_oracle as O
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1"); monkeypatch.setenv("MASTER_PORT", "29533")
+    monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("CODAE_DP_FORCE_ALLREDUCE", "1")
+    S, E, B = 3, 256, 2048
+    io = S * E
+    rng = np.random.default_rng(5)
+    data = rng.random((2 * B, io), dtype=np.float32)
+    sched = O.layer_schedule(io, io, 3, 3, False, "embedding")
+    params = O.init_params(sched, rng)
+    bm, _, _ = O.corrupter_tables([{"size": E, "position": s * E} for s in range(S)], 1)
+    mtu = rng.integers(0, S, (2 * B, 1)).astype(np.int32)
+    order = [torch.tensor(rng.permutation(2 * B)[:B], dtype=torch.int32, device=DEV) for _ in range(3)]
+    init_rccl_process_group(torch.device(DEV))
+    try:
+        outs = []
+        for native in (False, True):
+            tr = HipEmbeddingTrainer(sched, torch.tensor(data), torch.tensor(bm).to(torch.uint8), torch.tensor(mtu), 1e-3, 1e-4, 1.0,
+                                     max_batch=B, precision="bf16", device=DEV, distributed=True, native_dp=native)
+            assert tr.dp.native == native and len(tr.dp.buckets) == len(sched)
+            tr.load_params(params)
+            for idx in order:
+                tr.train_batch(idx, run=0)
+            eng = tr.engine
+            outs.append((eng.params.clone(), eng.adam_m.clone(), eng.adam_v.clone(), eng.shadow.clone(), eng.shadow_t.clone(), eng.read_scalars()))
+            del tr
+        for a, b2 in zip(outs[0][:5], outs[1][:5]):
+            assert torch.equal(a, b2)
+        assert outs[0][5] == outs[1][5] and outs[0][5][3] > 0
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("S,E,B", [(3, 128, 1000), (3, 320, 8192)], ids=["tile128x128", "tile256x192"])
 def test_fused_loss_epilogue_matches_separate_loss_kernel(monkeypatch, S, E, B):
     """bf16 training step with the MSE loss folded into the last forward GEMM vs the same step with
