@@ -326,11 +326,9 @@ __device__ __forceinline__ void gemm_bf16_pipe_tile(const GemmBf16& g, int tiles
             if (mine < lines) pf_val ^= *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(g.prefetch) + (mine << 7));
         }
     }
-    // (consumed by a store whose condition is never true - prefetch_bytes is positive - so the compiler keeps the loads and
-    // waits for them only at the kernel's exit)
-    auto consume_prefetch = [&]() {
-        if (g.prefetch != nullptr && pf_val == 0xFFA5FFA5u && g.prefetch_bytes < 0) *reinterpret_cast<volatile uint32_t*>(g.C) = pf_val;
-    };
+    // (consumed at the kernel's exits by an empty asm that names the register: the compiler keeps the loads and waits for
+    // them only there, after the epilogue's own stores have been issued)
+    auto consume_prefetch = [&]() { asm volatile("" ::"v"(pf_val)); };
     phase_barrier();          // every wave is past its last fragment read and every DMA has landed: LDS is free
     if constexpr (EPI == 3) {
         // Last forward layer of a training step (train_dae_on_embedding.py:206-223): y = acc + bias stays in registers.
