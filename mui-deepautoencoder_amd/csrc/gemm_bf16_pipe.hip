@@ -498,6 +498,29 @@ __device__ __forceinline__ void gemm_bf16_pipe_tile(const GemmBf16& g, int tiles
         constexpr int PITCH = BN * 2 + 16;
         static_assert(BM * PITCH <= 2 * BUF, "output tile must fit in the staging buffers");
         const float floor_v = g.relu ? 0.f : -__builtin_inff();
+        constexpr int CH = BN / 8, RL = NT / CH;
+        constexpr int ITER = (BM + RL - 1) / RL;
+        const int c = threadIdx.x % CH, rl = threadIdx.x / CH;
+        const int j = j0 + c * 8;
+        const int jc = j < g.N ? j : 0;
+        // ReLU mask of the data gradient: one BIT per element when the forward launch left them (g.relu_bits: 1 byte per lane
+        // and row instead of 16 - the saved activation is 25 MB per launch at C3 and comes from HBM), else the activation.
+        // The byte loads depend on nothing but indices: issued HERE, in front of the staging pass, their latency lies under it
+        // (behind the barrier that ends the staging they were the first thing the write-out waited for).
+        const bool bit_mask = EPI != 1 && g.relu_bits != nullptr;
+        uint8_t hb[ITER];
+        if constexpr (EPI != 1) {
+            const uint8_t* bsrc = bit_mask ? g.relu_bits : reinterpret_cast<const uint8_t*>(g.A);
+            const int64_t bld = bit_mask ? g.ld_bits : 0;
+            if (bit_mask) {
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) {
+                    const int r = rl + it * RL;
+                    const bool ok = rl < RL && j < g.N && r < BM && i0 + r < g.M;
+                    hb[it] = bsrc[(int64_t)(ok ? i0 + r : 0) * bld + (ok ? (jc >> 3) : 0)];
+                }
+            }
+        }
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
@@ -519,9 +542,6 @@ __device__ __forceinline__ void gemm_bf16_pipe_tile(const GemmBf16& g, int tiles
                     }
             }
         __syncthreads();
-        constexpr int CH = BN / 8, RL = NT / CH;
-        const int c = threadIdx.x % CH, rl = threadIdx.x / CH;
-        const int j = j0 + c * 8;
         float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         {
             // Fully unrolled with predicated stores and UNCONDITIONAL loads from clamped addresses: the ReLU-mask loads
@@ -529,27 +549,12 @@ __device__ __forceinline__ void gemm_bf16_pipe_tile(const GemmBf16& g, int tiles
             // As a loop with one row per trip every trip waited for its own load: the data-gradient launch was 10 us
             // longer than the forward one.
             bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
-            constexpr int ITER = (BM + RL - 1) / RL;
-            // ReLU mask of the data gradient: one BIT per element when the forward launch left them (g.relu_bits: 1 byte per lane
-            // and row instead of 16 - the saved activation is 25 MB per launch at C3 and comes from HBM), else the activation
-            const bool bit_mask = EPI != 1 && g.relu_bits != nullptr;
             const bool relu_mask = EPI != 1 && !bit_mask && g.relu_src != nullptr;
             const bf16_t* hsrc = relu_mask ? g.relu_src : g.A;                 // (no mask: any valid 16-B aligned bytes)
             const int64_t hld = relu_mask ? g.ld_relu : 0;
-            const int jc = j < g.N ? j : 0;
-            const uint8_t* bsrc = bit_mask ? g.relu_bits : reinterpret_cast<const uint8_t*>(g.A);
-            const int64_t bld = bit_mask ? g.ld_bits : 0;
             uint4 hv[ITER];
-            uint8_t hb[ITER];
             if constexpr (EPI != 1) {
-                if (bit_mask) {
-#pragma unroll
-                    for (int it = 0; it < ITER; ++it) {
-                        const int r = rl + it * RL;
-                        const bool ok = rl < RL && j < g.N && r < BM && i0 + r < g.M;
-                        hb[it] = bsrc[(int64_t)(ok ? i0 + r : 0) * bld + (ok ? (jc >> 3) : 0)];
-                    }
-                } else {
+                if (!bit_mask) {
 #pragma unroll
                     for (int it = 0; it < ITER; ++it) {
                         const int r = rl + it * RL;
