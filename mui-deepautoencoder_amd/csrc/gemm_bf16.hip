@@ -715,16 +715,32 @@ static bool small_tile_64(const GemmBf16& g) {
     return (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) <= env().small_tile_max;
 }
 
+// Which kernel a (non-loss) launch takes: the ONE place that decides, used by gemm_bf16() itself and by whoever has to know in
+// advance (gemm_bf16_takes_relu_bits).  > 0: the pipelined kernel with that cfg (1 / 6: 256 x 192, 7: 128 x 192);
+// -64 / -128: the one-barrier kernel on 64 x 64 / 128 x 128 tiles.
+static int bf16_path(const GemmBf16& g) {
+    const int t = gemm_bf16_tile_big(g.M, g.N, g.split_k, g.b_mode == OP_KS || g.c_f32);
+    switch (t) {
+        case 3: return 1;               // 256 x 192, 8 waves, phase-pipelined, every wave loads
+        case 6: return 6;               // 256 x 192, 8 waves, LDS-DMA issued by one wave per SIMD (default)
+        case 7: return 7;               // (forced: 128 x 192 pipelined, forward form only)
+        default:                        // small problems: one-barrier double buffer
+            if (small_tile_64(g)) return -64;
+            // between the 64 x 64 tiles and the 256 x 192 tile, forward / data-gradient form: the pipelined kernel on 128 x 192
+            // tiles (tools/bench_gemm_fwd.py, us, 128 x 128 one-barrier / 128 x 192 pipelined: 4096 x 1536 x 1536 28.3 / 21.9,
+            // 3000 x 1536 x 1536 26.4 / 19.8, 8192 x 768 x 768 17.9 / 14.6; same bits)
+            if (g.a_mode == OP_KC && g.b_mode == OP_KC && !g.c_f32 && g.split_k == 1 && !env().no_deep_small) return 7;
+            return -128;
+    }
+}
+
 // a forward-form (k-contiguous operands, bf16 out, unsplit) launch with this output shape goes to a pipelined kernel (256 x 192 or
-// 128 x 192 tiles), whose epilogues write / read the 1-bit ReLU mask; mirrors the dispatch at the end of gemm_bf16()
+// 128 x 192 tiles), whose epilogues write / read the 1-bit ReLU mask
 bool gemm_bf16_takes_relu_bits(int M, int N) {
     if (env().gemm_dbg) return false;
-    const int t = gemm_bf16_tile_big(M, N, 1);
-    if (t == 3 || t == 6 || t == 7) return true;
     GemmBf16 probe{};
     probe.M = M; probe.N = N; probe.a_mode = OP_KC; probe.b_mode = OP_KC; probe.c_f32 = 0; probe.split_k = 1;
-    if (small_tile_64(probe)) return false;
-    return !env().no_deep_small;
+    return bf16_path(probe) > 0;
 }
 
 // rows of g.colsum_part the launch gemm_bf16(g) makes will write: one per tile along M of the tile it picks
@@ -769,19 +785,10 @@ int gemm_bf16(const GemmBf16& g, hipStream_t s) {
         if (small_tile_64(g)) return launch_cfg<64, 64, 2, 2>(g, s);
         return launch_cfg<128, 128, 2, 2>(g, s);
     }
-    const int t = gemm_bf16_tile_big(g.M, g.N, g.split_k, g.b_mode == OP_KS || g.c_f32);
-    switch (t) {
-        case 3: return gemm_bf16_pipe(g, 1, s);               // 256 x 192, 8 waves, phase-pipelined, every wave loads
-        case 6: return gemm_bf16_pipe(g, 6, s);               // 256 x 192, 8 waves, LDS-DMA issued by one wave per SIMD (default)
-        case 7: return gemm_bf16_pipe(g, 7, s);              // (forced: 128 x 192 pipelined, forward form only)
-        default:                                              // small problems: one-barrier double buffer
-            if (small_tile_64(g)) return launch_cfg<64, 64, 2, 2>(g, s);
-            // between the 64 x 64 tiles and the 256 x 192 tile, forward / data-gradient form: the pipelined kernel on 128 x 192
-            // tiles (tools/bench_gemm_fwd.py, us, 128 x 128 one-barrier / 128 x 192 pipelined: 4096 x 1536 x 1536 28.3 / 21.9,
-            // 3000 x 1536 x 1536 26.4 / 19.8, 8192 x 768 x 768 17.9 / 14.6; same bits)
-            if (g.a_mode == OP_KC && g.b_mode == OP_KC && !g.c_f32 && g.split_k == 1 && !env().no_deep_small) return gemm_bf16_pipe(g, 7, s);
-            return launch_cfg<128, 128, 2, 2>(g, s);
-    }
+    const int path = bf16_path(g);
+    if (path > 0) return gemm_bf16_pipe(g, path, s);
+    if (path == -64) return launch_cfg<64, 64, 2, 2>(g, s);
+    return launch_cfg<128, 128, 2, 2>(g, s);
 }
 
 #if defined(CODAE_DBG_5D) && (CODAE_DBG_5D & 2)
