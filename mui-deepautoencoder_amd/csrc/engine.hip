@@ -394,23 +394,25 @@ int run_wgrad_grouped(const codae_engine* e, const codae_buffers* b, int rows, b
 
 // Wide bf16 stack, single-GPU fused step: every layer's weight gradient in ONE launch of 256 x 192 tiles with K = the whole batch
 // (no split-K slabs, no reduce pass; sum g^2 from the epilogue), issued AFTER the data-gradient chain, which then has the chip to
-// itself.  Needs dA_l of every layer alive at once (n_dact > L) and enough tiles in total to fill the chip (C3: 48 tiles per
+// itself (defer_wgrad_mode).  Needs dA_l of every layer alive at once (n_dact > L) and enough tiles in total to fill the chip (C3: 48 tiles per
 // layer -> round 2 split K five ways: 47 MB of fp32 slabs written and read back per layer, 0.28 ms of reduce launches per step;
 // all ten together: 480 tiles on 256 CUs).  Small batches gain even more: their per-layer launches are all fixed cost (3 x 512 at the
 // reference's stock batch 128: 0.436 -> 0.402 ms/step; batch 512: 0.663 -> 0.433).
-bool defer_wgrad_ok(const codae_engine* e, int rows) {
+// 0: per-layer weight gradients; 1: one grouped launch of the pipelined 256 x 192 tile; 2: one grouped launch of the one-barrier
+// kernel on 128 x 128 / 64 x 128 / 64 x 64 tiles (run_wgrad_grouped: stacks too narrow to fill the chip with the big tile)
+int defer_wgrad_mode(const codae_engine* e, int rows) {
     if (e->prec != CODAE_PREC_BF16 || e->cfg.no_defer_wgrad || e->cfg.single_stream || e->L > CODAE_GROUP_MAX || e->n_dact <= e->L || rows < 64)
-        return false;
-    int total = 0, largest = 0;
+        return 0;
+    int total = 0, total_small = 0;
     for (int l = 0; l < e->L; ++l) {
-        const int t = ((e->out[l] + 255) / 256) * ((e->in[l] + 191) / 192);
-        total += t;
-        if (t > largest) largest = t;
-        if ((int64_t)rows * e->out[l] * 2 >= (int64_t)1 << 32 || (int64_t)rows * e->in[l] * 2 >= (int64_t)1 << 32) return false;
+        total += ((e->out[l] + 255) / 256) * ((e->in[l] + 191) / 192);
+        total_small += ((e->out[l] + 63) / 64) * ((e->in[l] + 63) / 64);
+        if ((int64_t)rows * e->out_ld[l] * 2 >= (int64_t)1 << 32 || (int64_t)rows * e->in_ld[l] * 2 >= (int64_t)1 << 32) return 0;
     }
-    (void)largest;      // (round 3 first kept the per-layer backward when one layer alone fills the chip - C5: 31.2 ms/step against 32.9
-                        //  grouped; with the 4 x 8 tile order of the pipelined kernel the grouped launch wins there too: 29.5 against 30.2)
-    return total >= 200;
+    // (round 3 first kept the per-layer backward when one layer alone fills the chip - C5: 31.2 ms/step against 32.9 grouped; with
+    //  the 4 x 8 tile order of the pipelined kernel the grouped launch wins there too: 29.5 against 30.2)
+    if (total >= 200) return 1;
+    return total_small >= 128 ? 2 : 0;
 }
 
 int run_wgrad_deferred(const codae_engine* e, const codae_buffers* b, int rows, hipStream_t s) {
@@ -663,15 +665,16 @@ int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi
     // gain, 1.83 / 1.84 vs 1.82 ms at the time; every GEMM on the caller's stream with only the reduces beside
     // them - 0.27 ms slower: each cross-queue event costs ~10 us.)
     // (the drop-in backward - codae_backward over the whole stack without an input gradient - takes the same schedule)
-    if ((step_mode || dx == nullptr) && join && lo == 0 && hi == h->L && h->L >= 2 && defer_wgrad_ok(h, rows)) {
-        // data-gradient chain alone on the chip, then all weight gradients in one launch (see defer_wgrad_ok); one stream
+    const int defer = ((step_mode || dx == nullptr) && join && lo == 0 && hi == h->L && h->L >= 2) ? defer_wgrad_mode(h, rows) : 0;
+    if (defer != 0) {
+        // data-gradient chain alone on the chip, then all weight gradients in one launch (see defer_wgrad_mode); one stream
         int rc = join_side(h, s);                  // (an earlier bucketed backward may have left work on the side stream)
         if (rc) return rc;
         for (int l = hi - 1; l >= 1; --l) {
             rc = run_dgrad(h, b, l, rows, nullptr, s);
             if (rc) return rc;
         }
-        rc = run_wgrad_deferred(h, b, rows, s);
+        rc = defer == 1 ? run_wgrad_deferred(h, b, rows, s) : run_wgrad_grouped(h, b, rows, h->norm_in_backward, s);
         if (rc) return rc;
         return finish_bias(h, b, s, h->norm_in_backward);
     }

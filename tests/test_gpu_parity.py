@@ -860,6 +860,9 @@ def test_two_stream_step_matches_single_stream_over_many_steps(monkeypatch):
     mtu = rng.integers(0, S, (N, 1)).astype(np.int32)
     order = [torch.tensor(rng.permutation(N)[:B], dtype=torch.int32, device=DEV) for _ in range(steps)]
     runs = []
+    # (the per-layer backward: what the data-parallel step and CODAE_NO_DEFER_WGRAD=1 run; the single-GPU default - every weight
+    #  gradient in one grouped launch - has no second stream at all: tools/soak.py and the determinism tests cover it)
+    monkeypatch.setenv("CODAE_NO_DEFER_WGRAD", "1")
     for single in (True, False):
         if single:
             monkeypatch.setenv("CODAE_SINGLE_STREAM", "1")
