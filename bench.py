@@ -176,8 +176,15 @@ def main():
     args.embedding = ce if args.embedding is None else args.embedding
     args.batch = cb if args.batch is None else args.batch
 
+    # thread pools no wider than the container's CPU quota, set before numpy / torch create them (codae/hostcpu.py;
+    # BENCH_NO_THREAD_FIT=1: ablation - the default pools of one thread per visible cpu)
+    from codae.hostcpu import cap_thread_env, fit_host_threads
+    fit = os.environ.get("BENCH_NO_THREAD_FIT") != "1"
+    if fit:
+        cap_thread_env()
     import numpy as np
     import torch
+    host_share = fit_host_threads() if fit else None      # before the first wide torch CPU op: see its docstring (CFS throttling = "cold" 24 ms steps)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -385,6 +392,7 @@ def main():
             "final_loss": loss, "final_grad_norm": gnorm,
             "host_enqueue_ms_per_step": 1e3 * enqueue_s / args.steps,
             "host_enqueue_done_ms_first_steps": enq_marks, "ramp_up_step_ms": ramp_ms,
+            "host_cpu_share": host_share, "host_threads": torch.get_num_threads(),
             "step_path": step_path,
             "f32_parity": f32_parity,
             **({"step_done_ms": step_times} if step_times is not None else {}),

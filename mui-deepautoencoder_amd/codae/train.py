@@ -25,6 +25,8 @@ valid for its own shards only until gather_params() is called (checkpoint, read-
 """
 import torch
 
+from .hostcpu import fit_host_threads, host_cpu_share  # noqa: F401  (re-exported: scripts and bench.py import them here)
+
 
 class SubsetEpochSampler:
     """Batches of dataset row indices in the order
@@ -41,9 +43,49 @@ class SubsetEpochSampler:
     def __len__(self):
         return (len(self.indices) + self.batch_size - 1) // self.batch_size
 
-    def __iter__(self):
+    def _epoch_order(self):
         torch.empty((), dtype=torch.int64).random_()          # DataLoader iterator's base seed
-        order = self.indices[torch.randperm(len(self.indices))]
+        # torch.randperm on the CPU draws the same permutation whatever the thread count; with one thread it takes 0.4 ms for
+        # 131 072 rows, with one per visible cpu of a GPU box 4-10 ms and the container's CPU quota (fit_host_threads above;
+        # tools/abl/randperm_cost.py, tools/bench_script_loop.py)
+        n_threads = torch.get_num_threads()
+        if n_threads > 1:
+            torch.set_num_threads(1)
+        try:
+            perm = torch.randperm(len(self.indices))
+        finally:
+            if n_threads > 1:
+                torch.set_num_threads(n_threads)
+        return self.indices[perm]
+
+    def __iter__(self):
+        order = self._epoch_order()
+        for o in range(0, len(order), self.batch_size):
+            yield order[o:o + self.batch_size]
+
+    def device_batches(self, device, dtype=torch.int32):
+        """The same batches as iterating the sampler (same draws from torch's default generator), as views of ONE device tensor
+        holding the epoch's whole order: one host-to-device copy per epoch instead of one per step.  (A per-step `.to(device)`
+        of a pageable host tensor is a synchronous copy ordered behind the previous step's kernels: the host can never run
+        ahead of the device, which costs the step its enqueue time - tools/bench_script_loop.py.)"""
+        order = self._epoch_order().to(dtype)
+        if torch.device(device).type == "cuda":
+            # one pinned staging buffer and one device buffer, both kept: the copy is ordered on the current stream behind the
+            # steps that still read the previous epoch's order, and the host only waits for the PREVIOUS copy before reusing the
+            # staging buffer (allocating / freeing pinned memory per epoch synchronises the device)
+            st = getattr(self, "_stage", None)
+            if st is None or st[0].numel() != order.numel() or st[0].dtype != order.dtype or st[1].device != torch.device(device):
+                st = (torch.empty(order.numel(), dtype=order.dtype).pin_memory(), torch.empty(order.numel(), dtype=order.dtype, device=device),
+                      torch.cuda.Event())
+                self._stage = st
+            else:
+                st[2].synchronize()
+            st[0].copy_(order)
+            st[1].copy_(st[0], non_blocking=True)
+            st[2].record()
+            order = st[1]
+        else:
+            order = order.to(device)
         for o in range(0, len(order), self.batch_size):
             yield order[o:o + self.batch_size]
 
@@ -345,6 +387,7 @@ class HipEmbeddingTrainer:
         """use_graph: replay the fused step from a hipGraph (codae_train_step_graph): for launch-bound shapes
         (small batches); single process only - the bucketed data-parallel step is not captured."""
         from .hip.engine import DaeEngine
+        fit_host_threads()      # the loop that feeds this trainer must not get its container CPU-throttled (codae/hostcpu.py)
         self.device = torch.device(device)
         self.engine = DaeEngine(schedule, max_batch, precision, self.device)
         self.data = data.to(device=self.device, dtype=torch.float32).contiguous()

@@ -15,19 +15,22 @@ import math
 import os
 import sys
 
-import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from codae.hostcpu import cap_thread_env                                   # noqa: E402
+cap_thread_env()        # BLAS / OpenMP pools no wider than the container's CPU quota, before numpy and torch create them
+
+import numpy as np                                                       # noqa: E402
 import pandas as pd
 import torch
 import yaml
 from sklearn.preprocessing import MinMaxScaler
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 from codae.dataset import MixedVariableDataset                      # noqa: E402
 from codae.hip import HipError                                      # noqa: E402
 from codae.model import MixedVariableDenoisingAutoencoder           # noqa: E402
 from codae.tool import CombinedCriterion, Corrupter, Normalizer, get_date, set_logging  # noqa: E402
-from codae.train import SubsetEpochSampler                          # noqa: E402
+from codae.train import SubsetEpochSampler, fit_host_threads        # noqa: E402
 
 
 def parse():
@@ -57,6 +60,7 @@ def print_table(names, table, k_max):
 def main():
     print("===== Train DAE on Abalone data =====")
     args = parse()
+    fit_host_threads()              # torch / BLAS pools no wider than the container's CPU quota (codae/train.py)
     log = set_logging(logging_level=(logging.DEBUG if args.debug else logging.INFO), log_file_path="log/")
     with open(args.config, 'r') as stream:
         config = yaml.safe_load(stream)
@@ -113,8 +117,7 @@ def main():
         accounting of the reference (monitor criterion, get_partial, get_per_k: :227-236) is one kernel adding into fp64 tables
         that are read once per sweep."""
         for run in range(corrupter.nb_run):
-            for batch_indices in sampler:
-                rows = batch_indices.to(device)
+            for rows in sampler.device_batches(device, dtype=torch.long):
                 input_data = dataset.data[rows]
                 ids = corrupter.mask_ids(rows, run)
                 masks, fmask = corrupter.get_masks(rows, run)

@@ -19,16 +19,19 @@ import os
 import random
 import sys
 
-import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from codae.hostcpu import cap_thread_env                                   # noqa: E402
+cap_thread_env()        # BLAS / OpenMP pools no wider than the container's CPU quota, before numpy and torch create them
+
+import numpy as np                                                       # noqa: E402
 import torch
 import yaml
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 from codae.hip import HipError                                            # noqa: E402
 from codae.model.schedule import linear_stack                             # noqa: E402
 from codae.tool import Corrupter, RankingLoss, display_info, get_date, load_dataset_of_embeddings, set_logging  # noqa: E402
-from codae.train import HipEmbeddingTrainer, SubsetEpochSampler, shard_batch   # noqa: E402
+from codae.train import HipEmbeddingTrainer, SubsetEpochSampler, fit_host_threads, shard_batch   # noqa: E402
 
 
 def parse():
@@ -46,6 +49,7 @@ def parse():
 
 def main():
     args = parse()
+    fit_host_threads()              # torch / BLAS pools no wider than the container's CPU quota (codae/train.py)
     log = set_logging(logging_level=(logging.DEBUG if args.debug else logging.INFO), log_file_path="log/")
     with open(args.config, 'r') as stream:
         config = yaml.safe_load(stream)
@@ -117,13 +121,13 @@ def main():
 
     for epoch in range(epochs):
         log.info("===================================================== EPOCH = %d" % epoch)
-        for batch_indices in train_sampler:
+        for batch_indices in train_sampler.device_batches(device):      # one index copy per epoch, int32, on the device
             shard = shard_batch(batch_indices, rank, world)
             if shard is None:                   # fewer rows than ranks (ragged last batch): skipped by every rank
                 nb_skipped = len(batch_indices)
                 log.info("skipping a global batch of %d rows on %d ranks" % (nb_skipped, world))
                 continue
-            trainer.train_batch(shard.to(device=device, dtype=torch.int32), run=0, global_rows=len(batch_indices))
+            trainer.train_batch(shard.contiguous(), run=0, global_rows=len(batch_indices))
         sq, sqp = trainer.epoch_sums()
         book["ftl"].append(np.sqrt(sq / (dataset.nb_predictor * nb_train)))
         book["ptl"].append(np.sqrt(sqp / (nb_train * dataset.nb_predictor / S)))
@@ -133,8 +137,7 @@ def main():
         # validation (reference :241-261) stays on the device: forward + metric sums in the engine, the rank metric as
         # batched GEMMs against the validation inventory with the masks taken from the Corrupter's device tables; one
         # read-back per epoch instead of a mask expansion, two .tolist() and a host sync per batch
-        for batch_indices in validation_sampler:
-            idx = batch_indices.to(device=device, dtype=torch.int32)
+        for idx in validation_sampler.device_batches(device):
             y = trainer.eval_batch(idx, run=0, want_y=True)
             ranking_loss.add(y, idx, corrupter, run=0)
         rl = ranking_loss.total()

@@ -12,6 +12,11 @@ for p in (ROOT, PKG):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # torch / OpenBLAS pools sized for every VISIBLE cpu burn the container's CFS quota and get every process in it
+    # throttled - the GPU tests' enqueue threads and the bench subprocess included (codae.train.fit_host_threads)
+    from codae.hostcpu import cap_thread_env, fit_host_threads
+    cap_thread_env()                 # (inherited by the bench / script / rank subprocesses the GPU tests start)
+    fit_host_threads()
 
 
 def _has_gpu():

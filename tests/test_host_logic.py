@@ -277,6 +277,37 @@ def test_epoch_sampler_matches_torch_dataloader_order():
     mine = SubsetEpochSampler(subset, 16)
     got = [b.tolist() for _ in range(2) for b in mine]
     assert got == ref and len(mine) == 5
+    # the one-copy-per-epoch form the scripts iterate (views of the whole epoch order): same draws, same batches
+    torch.manual_seed(11)
+    moved = [b.tolist() for _ in range(2) for b in mine.device_batches("cpu")]
+    assert moved == ref
+    assert next(iter(mine.device_batches("cpu"))).dtype == torch.int32
+    assert next(iter(mine.device_batches("cpu", dtype=torch.long))).dtype == torch.long
+
+
+def test_host_threads_follow_the_cpu_quota_and_are_never_raised(tmp_path, monkeypatch):
+    """fit_host_threads caps torch's intra-op pool at min(affinity, cgroup quota) and never widens it (why it exists: a
+    256-thread pool under a 16-cpu CFS quota gets the whole container throttled, GPU enqueue thread included)."""
+    import builtins
+    from codae import train as T
+    share = T.host_cpu_share()
+    assert 1 <= share <= len(os.sched_getaffinity(0))
+    before = torch.get_num_threads()
+    try:
+        assert T.fit_host_threads() == share and torch.get_num_threads() == min(before, share)
+        torch.set_num_threads(1)
+        T.fit_host_threads()
+        assert torch.get_num_threads() == 1
+        # a cgroup-v2 quota of 2.5 cpus counts as 2; "max" leaves the affinity mask
+        real_open = builtins.open
+        for text, want in (("250000 100000\n", min(2, len(os.sched_getaffinity(0)))), ("max 100000\n", len(os.sched_getaffinity(0)))):
+            f = tmp_path / "cpu.max"
+            f.write_text(text)
+            monkeypatch.setattr(builtins, "open", lambda p, *a, **k: real_open(str(f) if p == "/sys/fs/cgroup/cpu.max" else p, *a, **k))
+            assert T.host_cpu_share() == want
+            monkeypatch.setattr(builtins, "open", real_open)
+    finally:
+        torch.set_num_threads(before)
 
 
 def _load_check_isa():
