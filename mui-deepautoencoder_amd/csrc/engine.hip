@@ -45,6 +45,7 @@ void env_reload() {
     e.no_defer_wgrad = getenv("CODAE_NO_DEFER_WGRAD") != nullptr;
     e.no_prefetch = getenv("CODAE_NO_PREFETCH") != nullptr;
     e.no_relu_bits = getenv("CODAE_NO_RELU_BITS") != nullptr;
+    if (const char* k = getenv("CODAE_F32_GEMM")) e.f32_gemm = k[0] == 'n' ? 1 : (k[0] == 'x' ? 2 : 0);
     if (const char* k = getenv("CODAE_SMALL_TILE_MAX")) e.small_tile_max = atoi(k);
     if (const char* k = getenv("CODAE_SMALL_STAGES")) e.small_stages = atoi(k) == 2 ? 2 : 4;
     g_env = e;
@@ -239,6 +240,18 @@ int choose_split_k_f32(int N, int K, int rows) {
     if (env().wgrad_splitk > 0) return env().wgrad_splitk <= rows / 32 ? env().wgrad_splitk : 1;
     if (rows <= 1024) return 1;
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+    if (env().f32_gemm != 1 && N % 4 == 0 && K % 4 == 0) {
+        // the bf16-plane kernel (gemm_f32x3.hip) runs ONE workgroup per CU: the split that leaves the last round of 256 fullest
+        // (1536 x 1536: 144 tiles x 7 = 1008 of 1024 slots), at least 8 K-tiles per range, the smallest such split on a tie
+        int best = 1;
+        double best_fill = 0.0;
+        for (int s = 1; s <= 8 && s <= rows / 256; ++s) {
+            const int wgs = tiles * s, rounds = (wgs + 255) / 256;
+            const double fill = (double)wgs / (256.0 * rounds);
+            if (fill > best_fill + 0.02) { best_fill = fill; best = s; }
+        }
+        return best;
+    }
     int s = (384 + tiles / 2) / tiles;
     if (s > 8) s = 8;
     if (s > rows / 256) s = rows / 256;

@@ -83,6 +83,78 @@ def test_wgrad_f32(hip, M, N, K):
     assert np.abs(f64(db) - f64(dy).sum(0)).max() < 1e-4 * M ** 0.5
 
 
+@pytest.fixture
+def f32_gemm_mode(hip, monkeypatch):
+    """CODAE_F32_GEMM for one test (native = fp32 MFMA, x3 = three bf16 planes per operand), restored afterwards"""
+    def set_mode(mode):
+        monkeypatch.setenv("CODAE_F32_GEMM", mode)
+        hip.check(hip.lib().codae_reload_env())
+    yield set_mode
+    monkeypatch.delenv("CODAE_F32_GEMM", raising=False)
+    hip.check(hip.lib().codae_reload_env())
+
+
+# (M, N, K): K in whole 32-deep tiles and 16-B aligned rows are what gemm_f32x3.hip takes; ragged M / N exercise its clamped loads
+SHAPES_X3 = [(128, 128, 32), (200, 132, 64), (1000, 388, 384), (513, 1536, 1536), (2048, 1536, 512)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES_X3)
+def test_f32_gemm_from_bf16_planes_matches_fp64_as_closely_as_the_fp32_mfma_kernel(hip, f32_gemm_mode, M, N, K):
+    """gemm_f32x3.hip (fp32 operands cut into three bf16 planes, six bf16 MFMA products, fp32 accumulation) in the three GEMM
+    forms of the step - forward (bias + ReLU), data gradient (ReLU mask), weight gradient (both operands k-strided) - against
+    float64, and against gemm_f32.hip on the same inputs: its rms error may not exceed the fp32-MFMA kernel's by more than 10 %
+    (measured: 10-15 % BELOW it), and the north-star tolerance rtol 1e-3 / atol 1e-5 * sqrt(K) holds outright."""
+    g = torch.Generator(device="cpu").manual_seed(M + 3 * N + 7 * K)
+    x = torch.randn(M, K, generator=g).to(dev()); W = torch.randn(N, K, generator=g).to(dev()); b = torch.randn(N, generator=g).to(dev())
+    dy = torch.randn(M, N, generator=g).to(dev()); h = torch.randn(M, K, generator=g).to(dev())
+    ref = [np.maximum(f64(x) @ f64(W).T + f64(b), 0), (f64(dy) @ f64(W)) * (f64(h) > 0), f64(dy).T @ f64(x)]
+    rms = {}
+    for mode in ("native", "x3"):
+        f32_gemm_mode(mode)
+        y = torch.full((M, N), float("nan"), device=dev()); dx = torch.full((M, K), float("nan"), device=dev())
+        dW = torch.full((N, K), float("nan"), device=dev()); db = torch.full((N,), float("nan"), device=dev())
+        L, s = hip.lib(), hip.current_stream()
+        hip.check(L.codae_linear_f32(hip.ptr(x), hip.ptr(W), hip.ptr(b), hip.ptr(y), M, N, K, 1, s))
+        hip.check(L.codae_dgrad_f32(hip.ptr(dy), hip.ptr(W), hip.ptr(h), hip.ptr(dx), M, N, K, s))
+        hip.check(L.codae_wgrad_f32(hip.ptr(dy), hip.ptr(x), hip.ptr(dW), hip.ptr(db), M, N, K, s))
+        sync()
+        got = [f64(y), f64(dx), f64(dW)]
+        for a, r, depth in zip(got, ref, (K, N, M)):
+            assert np.allclose(a, r, rtol=1e-3, atol=1e-5 * np.sqrt(depth)), (mode, np.abs(a - r).max())
+        rms[mode] = [float(np.sqrt(np.mean((a - r) ** 2))) for a, r in zip(got, ref)]
+    for form in range(3):
+        assert rms["x3"][form] <= 1.1 * rms["native"][form] + 1e-9, (form, rms)
+
+
+def test_f32_gemm_from_bf16_planes_is_exact_on_integers_and_deterministic(hip, f32_gemm_mode):
+    """integer-valued operands (|a| < 2^24 splits exactly into three bf16 planes; every product and partial sum is exact): the
+    result equals the float64 product BIT FOR BIT - any wrong plane pairing, lane or fragment mapping shows - and two launches
+    give the same bits."""
+    f32_gemm_mode("x3")
+    for M, N, K in [(256, 256, 256), (300, 132, 992), (128, 384, 4096)]:
+        g = torch.Generator(device="cpu").manual_seed(M)
+        x = torch.randint(-3000, 3000, (M, K), generator=g).float().to(dev())          # 12 significant bits: planes 0 and 1 both in use
+        W = torch.randint(-40, 40, (N, K), generator=g).float().to(dev())
+        y = torch.empty(M, N, device=dev()); y2 = torch.empty(M, N, device=dev())
+        hip.check(hip.lib().codae_linear_f32(hip.ptr(x), hip.ptr(W), None, hip.ptr(y), M, N, K, 0, hip.current_stream()))
+        hip.check(hip.lib().codae_linear_f32(hip.ptr(x), hip.ptr(W), None, hip.ptr(y2), M, N, K, 0, hip.current_stream()))
+        sync()
+        assert np.array_equal(f64(y), f64(x) @ f64(W).T), (M, N, K)
+        assert torch.equal(y, y2)
+
+
+def test_f32_gemm_dispatch_keeps_unaligned_and_small_shapes_on_the_fp32_mfma_kernel(hip, f32_gemm_mode):
+    """CODAE_F32_GEMM=x3 forces the plane kernel only where it is legal: K not in whole 32-deep tiles (abalone's 11-wide
+    layers), rows that are not 16-byte aligned - those launches still run, on gemm_f32.hip, and give the fp64 answer."""
+    f32_gemm_mode("x3")
+    for M, N, K in [(37, 11, 11), (130, 200, 77), (64, 48, 30)]:
+        g = torch.Generator(device="cpu").manual_seed(K)
+        x = torch.randn(M, K, generator=g).to(dev()); W = torch.randn(N, K, generator=g).to(dev()); y = torch.empty(M, N, device=dev())
+        hip.check(hip.lib().codae_linear_f32(hip.ptr(x), hip.ptr(W), None, hip.ptr(y), M, N, K, 0, hip.current_stream()))
+        sync()
+        assert np.allclose(f64(y), f64(x) @ f64(W).T, rtol=1e-4, atol=1e-4)
+
+
 def test_linear_f32_full_size(hip):
     """BASELINE config 3x512, batch 8192: one encoder GEMM; checked on a row/column sample in float64
     and by linearity (f(a x1 + x2) = a f(x1) + f(x2) without bias)."""
