@@ -42,7 +42,14 @@ N_IN, N_OUT = 4, 4
 LR, WD, CLIP = 1e-5, 1e-4, 1.0
 CONFIGS = {"c2": (3, 128, 1024), "c3": (3, 512, 8192), "c5": (6, 1024, 16384)}
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
-PEAK_F32_TFLOPS = 157.3
+PEAK_F32_TFLOPS = 157.3        # dense fp32 MFMA (v_mfma_f32_32x32x2_f32): the roofline of gemm_f32.hip
+# the fp32 engine's large GEMMs run on gemm_f32x3.hip: each fp32 product = six bf16 MFMA products (three bf16 planes per operand,
+# fp32 accumulation), so their roofline is a sixth of the bf16 MFMA peak; CODAE_F32_GEMM=native puts them back on the fp32 MFMA
+PEAK_F32_VIA_BF16_TFLOPS = PEAK_BF16_TFLOPS / 6.0
+
+
+def f32_peak_tflops():
+    return PEAK_F32_TFLOPS if os.environ.get("CODAE_F32_GEMM", "")[:1] == "n" else PEAK_F32_VIA_BF16_TFLOPS
 
 
 def square_schedule(io, nb_in, nb_out):
@@ -367,15 +374,19 @@ def main():
         f32_parity = {"ms_per_step": 1e3 * t32 / n32, "samples_per_s": B * n32 / t32, "steps": n32, "warmup": w32,
                       "tflops": fps32 * B * n32 / t32 / 1e12,
                       "frac_of_157.3TF": fps32 * B * n32 / t32 / (PEAK_F32_TFLOPS * 1e12),
+                      "roofline_tflops": f32_peak_tflops(), "frac": fps32 * B * n32 / t32 / (f32_peak_tflops() * 1e12),
                       "final_loss": tr32.last_loss_and_grad_norm()[0],
-                      "note": "same workload, CODAE_PREC_F32 engine (v_mfma_f32_32x32x2_f32, exact fp32): the mode the "
-                              "reference replays at rtol 1e-3 / atol 1e-5 run in"}
+                      "note": "same workload, CODAE_PREC_F32 engine: the mode the reference replays at rtol 1e-3 / atol 1e-5 run "
+                              "in.  Its GEMMs take fp32 operands and give fp32-accurate products from three bf16 planes per "
+                              "operand / six bf16 MFMA products / fp32 accumulation (gemm_f32x3.hip; roofline = bf16 MFMA peak / 6 "
+                              "= 416.7 TFLOP/s; frac_of_157.3TF > 1 = faster than the fp32 MFMA could go); CODAE_F32_GEMM=native "
+                              "= v_mfma_f32_32x32x2_f32 throughout"}
         del tr32
 
     if rank == 0:
         fps = flops_per_sample(schedule)
         value = B * world * args.steps / elapsed
-        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else f32_peak_tflops()
         out = {
             "metric": "training samples/sec at 3x512-dim input, batch 8192" if (slots, emb, B) == (S, E, BATCH)
                       else "training samples/sec at %dx%d-dim input, batch %d" % (slots, emb, B),

@@ -18,8 +18,9 @@
 // Same interface and epilogue as gemm_f32.hip (GemmF32: strided operands, bias, ReLU, ReLU mask, per-64-row column sums,
 // split-K slabs, device-side row count).  Tile 128 x 128 x 32 per 512-thread workgroup, each of the 2 x 4 waves a 64 x 32 sub-tile of
 // 4 x 2 MFMA tiles (48 MFMAs per K-tile).  Global loads run two K-tiles ahead in two register sets; the split (3 v_cvt_pk_bf16_f32,
-// 4 shifts / masks, 4 subtractions per pair of values) and the LDS stores of tile t+1 are issued BETWEEN the MFMAs of tile t (the
-// matrix pipe runs them while the wave issues on), into the other of two LDS buffers: one barrier per K-tile.  96 KB of
+// 4 shifts / masks, 4 subtractions per pair of values) and the LDS stores of tile t+1 are issued among the first half of tile t's
+// MFMAs (the matrix pipe runs them while the wave issues on), into the other of two LDS buffers; then the one barrier of the
+// K-tile, the fragment reads of tile t+1 (a second fragment register set) and the second half of tile t's MFMAs over them.  96 KB of
 // LDS: one workgroup = two waves per SIMD per CU (with 4 waves of 64 x 64, one per SIMD, nothing covered a wave's LDS stores
 // and round trips: 275 us for the 8192 x 1536 x 1536 forward form, of which the stores alone were 107).
 #include "codae_common.h"
@@ -48,6 +49,15 @@ typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
 // a 64-B half of the bank row, and T puts the four of them on its four different 16-B slots: conflict-free.
 __device__ __forceinline__ int chunk_slot(int row, int chunk) { return chunk ^ ((0 - (row >> 2)) & 3); }
 
+// Plane image of a ROW-contiguous operand (!KC: element(r, k) = P[k * ks + r], the weight matrix in the data gradient, both operands
+// of the weight gradient): k-major, [32 k-rows][128 rows] bf16, 256 B per k-row, read with the transposing ds_read_b64_tr_b16 (the
+// layout and swizzle of the bf16 kernels' k-strided half images, gemm_bf16_halftile.h): the 16-row (32-B) blocks of k-row kr are
+// stored at block ^ key(kr), key = (kr & 3) | ((kr >> 3) & 1) << 2, so the 8 k-rows a 32-lane half of the transposed read
+// touches fall on 8 different 32-B slots; a store (8 B = 4 rows of one k-row per lane, 16 lanes = 128 contiguous bytes) stays
+// inside one 128-B window.  Storing this operand row-major like the other kind cost 12 ds_write_b32 per thread with 64-B global
+// segments: the 1536 x 1536 x 8192 weight gradient ran 400 us, the forward form of the same size 186.
+__device__ __forceinline__ int ks_block(int block, int kr) { return block ^ ((kr & 3) | (((kr >> 3) & 1) << 2)); }
+
 // two fp32 values -> their three bf16 planes, each as one packed pair (low half = x), round-to-nearest-even at every cut
 // (v_cvt_pk_bf16_f32); the two subtractions are exact in fp32
 __device__ __forceinline__ void split_pair(float x, float y, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
@@ -67,7 +77,8 @@ __device__ __forceinline__ void split_pair(float x, float y, uint32_t& p0, uint3
 // feed output rows / columns the epilogue does not store.  No branch anywhere: with a branch around a load the compiler
 // loses count of the loads in flight and drains them all (s_waitcnt vmcnt(0)) at every join - the prefetch would be gone.
 //   KC : element(r, k) = P[r * rs + k]   thread -> row t >> 2, k 8 (t & 3) .. + 7: reg[c]
-//   !KC: element(r, k) = P[k * ks + r]   thread -> k 2 (t & 15) + kk, rows 4 (t >> 4) .. + 3   (kk = 0, 1): reg[4 kk + c]
+//   !KC: element(r, k) = P[k * ks + r]   thread -> k 2 (t >> 5) + kk, rows 4 (t & 31) .. + 3   (kk = 0, 1): reg[4 kk + c]
+//        (32 consecutive lanes read the 512 contiguous bytes of one k-row)
 template <bool KC>
 __device__ __forceinline__ void x3_load(float (&reg)[8], const float* __restrict__ P, int64_t rs, int64_t ks, int r0, int k0,
                                         int R, int t) {
@@ -79,11 +90,11 @@ __device__ __forceinline__ void x3_load(float (&reg)[8], const float* __restrict
         reg[0] = v.x; reg[1] = v.y; reg[2] = v.z; reg[3] = v.w;
         reg[4] = u.x; reg[5] = u.y; reg[6] = u.z; reg[7] = u.w;
     } else {
-        int r = r0 + 4 * (t >> 4);
+        int r = r0 + 4 * (t & 31);
         r = r + 4 <= R ? r : R - 4;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const int k = k0 + 2 * (t & 15) + kk;
+            const int k = k0 + 2 * (t >> 5) + kk;
             const float4 v = *reinterpret_cast<const float4*>(P + (int64_t)k * ks + r);
             reg[4 * kk + 0] = v.x; reg[4 * kk + 1] = v.y; reg[4 * kk + 2] = v.z; reg[4 * kk + 3] = v.w;
         }
@@ -92,10 +103,20 @@ __device__ __forceinline__ void x3_load(float (&reg)[8], const float* __restrict
 
 // A thread's 8 values, split and stored into the operand's three plane images.
 //   KC : the 8 k-values of row t >> 2: one 16-B chunk per plane (ds_write_b128; 8 consecutive lanes fill 128 consecutive bytes)
-//   !KC: rows 4 (t >> 4) .. + 3, the k pair 2 (t & 15), + 1 of each: one dword per plane and row (ds_write_b32; a 32-lane group
-//        covers two rows' 64 bytes = 2-way on the 128-B store window, which costs a ds_write_b32 nothing)
+//   !KC: k-rows 2 (t >> 5), + 1, rows 4 (t & 31) .. + 3 of each: 8 B per plane and k-row into the k-major image (ds_write_b64)
 template <bool KC>
 __device__ __forceinline__ void x3_store(lds_c* opnd, const float (&reg)[8], int t) {
+    if constexpr ((X3_DBG & 32) != 0) {
+        // timing only: the same bytes through ds_write_addtid_b32 (no address VGPR; lane l writes dword l of a 256-B segment at M0 + offset)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t a, b, c;
+            split_pair(reg[2 * q], reg[2 * q + 1], a, b, c);
+            asm volatile("s_mov_b32 m0, %3\n\tds_write_addtid_b32 %0 offset:0\n\tds_write_addtid_b32 %1 offset:8192\n\tds_write_addtid_b32 %2 offset:16384"
+                         :: "v"(a), "v"(b), "v"(c), "s"((uint32_t)(uintptr_t)opnd + 256u * (uint32_t)(4 * __builtin_amdgcn_readfirstlane(t >> 6) + q)) : "memory", "m0");
+        }
+        return;
+    }
     if constexpr (KC) {
         const int row = t >> 2;
         lds_c* dst = opnd + row * 64 + (chunk_slot(row, t & 3) << 4);
@@ -110,26 +131,45 @@ __device__ __forceinline__ void x3_store(lds_c* opnd, const float (&reg)[8], int
         *reinterpret_cast<lds_u32x4*>(dst + PLANE) = p1;
         *reinterpret_cast<lds_u32x4*>(dst + 2 * PLANE) = p2;
     } else {
-        const int kp = t & 15;
+        const int rg = t & 31;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = 4 * (t >> 4) + i;
-            lds_c* dst = opnd + row * 64 + (chunk_slot(row, kp >> 2) << 4) + (kp & 3) * 4;
-            uint32_t a, b, c;
-            split_pair(reg[i], reg[4 + i], a, b, c);
-            *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(dst) = a;
-            *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(dst + PLANE) = b;
-            *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(dst + 2 * PLANE) = c;
+        for (int kk = 0; kk < 2; ++kk) {
+            const int kr = 2 * (t >> 5) + kk;
+            lds_c* dst = opnd + kr * 256 + (ks_block(rg >> 2, kr) << 5) + (rg & 3) * 8;
+            u32x2 p0, p1, p2;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                uint32_t a, b, c;
+                split_pair(reg[4 * kk + 2 * q], reg[4 * kk + 2 * q + 1], a, b, c);
+                p0[q] = a; p1[q] = b; p2[q] = c;
+            }
+            *reinterpret_cast<lds_u32x2*>(dst) = p0;
+            *reinterpret_cast<lds_u32x2*>(dst + PLANE) = p1;
+            *reinterpret_cast<lds_u32x2*>(dst + 2 * PLANE) = p2;
         }
     }
 }
 
-// the 8 k-values lane `lane` feeds the MFMA with for 16-row tile `tile16` of a plane image
+// the 8 k-values lane `lane` feeds the MFMA with for 16-row tile `tile16` of a plane image: k = 8 (lane >> 4) .. + 7 of row
+// 16 tile16 + (lane & 15).  Row-major image: one ds_read_b128.  k-major image: two transposing reads (k-rows 8 g + q and + 4 of the
+// lane's 4-row piece; the hardware hands lane (r, g) the four k-values of row r from each)
+template <bool KC>
 __device__ __forceinline__ bf16x8 x3_frag(const lds_c* plane, int tile16, int lane) {
-    const int r = lane & 15, g = lane >> 4;
-    const int off = (16 * tile16 + r) * 64 + ((g ^ ((0 - (r >> 2)) & 3)) << 4);
-    const u32x4 v = *reinterpret_cast<const lds_u32x4*>(plane + off);
-    return __builtin_bit_cast(bf16x8, v);
+    if constexpr (KC) {
+        const int r = lane & 15, g = lane >> 4;
+        const int off = (16 * tile16 + r) * 64 + ((g ^ ((0 - (r >> 2)) & 3)) << 4);
+        const u32x4 v = *reinterpret_cast<const lds_u32x4*>(plane + off);
+        return __builtin_bit_cast(bf16x8, v);
+    } else {
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+        const int kr = 8 * g + q;
+        lds_c* src = const_cast<lds_c*>(plane) + kr * 256 + (ks_block(tile16, kr) << 5) + 8 * p;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4*>(src));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4*>(src + 4 * 256));
+        const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    }
 }
 
 template <bool A_KC, bool B_KC>
@@ -200,50 +240,68 @@ __global__ __launch_bounds__(XT) void gemm_f32x3_kernel(GemmF32 g) {
     __syncthreads();
     load(S0{}, 2);
 
-    // K-tile `tile` from LDS buffer CUR; meanwhile tile + 1 (register set CUR ^ 1) is split and stored into the other buffer - A
-    // after the first column block's MFMAs, B after the second's - and that register set is re-loaded with tile + 3
-    auto ktile = [&](int tile, auto cur_tag) {
-        constexpr int CUR = decltype(cur_tag)::value, NXT = CUR ^ 1;
-        const lds_c* cb = smem + CUR * XBUF;
-        lds_c* nb = smem + NXT * XBUF;
-        bf16x8 af[4][3], bf[2][3];
+    // Fragment registers of TWO K-tiles: the reads of tile t + 1 are issued in the middle of tile t's MFMAs, as soon as the barrier
+    // has published its planes, so that their LDS round trip (18 ds_read_b128 per wave, all 8 waves at once) lies under the
+    // second half of tile t's MFMAs.  (Read at the top of each K-tile, behind the barrier, the matrix pipe sat idle for the
+    // whole read phase: MFMAs + fragment reads alone ran at 56 % of the MFMA rate.)
+    bf16x8 af[2][4][3], bf[2][2][3];
+    auto read_frags = [&](auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
+        const lds_c* cb = smem + SET * XBUF;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) af[mt][p] = x3_frag(cb + p * PLANE, 4 * wr + mt, lane);
+            for (int mt = 0; mt < 4; ++mt) af[SET][mt][p] = x3_frag<A_KC>(cb + p * PLANE, 4 * wr + mt, lane);
         }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bf[nt][p] = x3_frag(cb + OPND + p * PLANE, 2 * wc + nt, lane);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+            for (int p = 0; p < 3; ++p) bf[SET][nt][p] = x3_frag<B_KC>(cb + OPND + p * PLANE, 2 * wc + nt, lane);
+    };
+    read_frags(S0{});
+
+    // K-tile `tile` (fragments already in register set CUR): the first column block's MFMAs with the split + LDS stores of tile + 1
+    // (register set CUR ^ 1 -> the other LDS buffer) issued between them; the barrier; the fragment reads of tile + 1; the second
+    // column block's MFMAs; the global loads of tile + 3.  One barrier per K-tile: a wave that stores tile + 2 into buffer CUR (next
+    // K-tile) has passed this one's barrier, which every wave reaches only after its last use of the fragments it read from CUR.
+    auto ktile = [&](int tile, auto cur_tag) {
+        constexpr int CUR = decltype(cur_tag)::value, NXT = CUR ^ 1;
+        lds_c* nb = smem + NXT * XBUF;
+        auto mma_block = [&](auto nt_tag) {
+            constexpr int nt = decltype(nt_tag)::value;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 // smallest products first (2^-16, 2^-16, 2^-16, 2^-8, 2^-8, 1 relative to a0 b0)
                 f32x4 c = acc[mt][nt];
                 if constexpr ((X3_DBG & 1) != 0) {
-                    asm volatile("" ::"v"(bf[nt][0]), "v"(bf[nt][1]), "v"(bf[nt][2]), "v"(af[mt][0]), "v"(af[mt][1]), "v"(af[mt][2]));
+                    asm volatile("" ::"v"(bf[CUR][nt][0]), "v"(bf[CUR][nt][1]), "v"(bf[CUR][nt][2]), "v"(af[CUR][mt][0]), "v"(af[CUR][mt][1]), "v"(af[CUR][mt][2]));
                     continue;
                 }
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nt][0], af[mt][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nt][1], af[mt][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nt][2], af[mt][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nt][0], af[mt][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nt][1], af[mt][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nt][0], af[mt][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[CUR][nt][0], af[CUR][mt][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[CUR][nt][1], af[CUR][mt][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[CUR][nt][2], af[CUR][mt][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[CUR][nt][0], af[CUR][mt][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[CUR][nt][1], af[CUR][mt][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[CUR][nt][0], af[CUR][mt][0], c, 0, 0, 0);
                 acc[mt][nt] = c;
             }
-            // (after the last tile this stages a dummy nobody reads)
-            if constexpr ((X3_DBG & 4) == 0) {
-                if (nt == 0) x3_store<A_KC>(nb, ra[NXT], t);
-                else x3_store<B_KC>(nb + OPND, rb[NXT], t);
-            }
+        };
+        mma_block(std::integral_constant<int, 0>{});
+        // (after the last tile this stages a dummy nobody reads)
+        if constexpr ((X3_DBG & 4) == 0) {
+            x3_store<A_KC>(nb, ra[NXT], t);
+            x3_store<B_KC>(nb + OPND, rb[NXT], t);
         }
+        // the register set just staged is free: re-load it with tile + 3 at once (a K-tile and a half ahead of its use; issued behind
+        // the second column block instead, one K-tile ahead, the wait for these loads was 17 % of the launch)
         if constexpr ((X3_DBG & 8) == 0) load(std::integral_constant<int, NXT>{}, tile + 3);
         __syncthreads();
-        // nothing moves across: without this the scheduler starts the NEXT K-tile's splits (plain VALU work on the register set
-        // whose loads were issued last) up here in the shadow of this K-tile's MFMAs, and the wait for those loads comes with it
+        // nothing moves across (in particular not the next K-tile's split, plain VALU work on the register set whose loads were
+        // issued last: the wait for those loads would come up here with it)
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(std::integral_constant<int, NXT>{});
+        __builtin_amdgcn_sched_barrier(0);      // (the scheduler sinks the reads below the MFMAs otherwise: fewer live registers)
+        mma_block(std::integral_constant<int, 1>{});
         __builtin_amdgcn_sched_barrier(0);
     };
     int tile = 0;
