@@ -22,6 +22,9 @@ N_GROUPED = int(sys.argv[5]) if len(sys.argv) > 5 else 10      # GEMMs inside on
 
 
 def classify(name):
+    if "gemm_f32x3_kernel" in name:        # fp32 products from three bf16 planes per operand: <A k-contiguous, B k-contiguous>
+        a = name[name.index("<") + 1:name.index(">")].replace(" ", "").split(",") if "<" in name else ["?", "?"]
+        return {("true", "true"): "gemm_f32x3_fwd", ("true", "false"): "gemm_f32x3_dgrad", ("false", "false"): "gemm_f32x3_wgrad"}.get(tuple(a[:2]), "gemm_f32x3")
     if "gemm_bf16_pipe_grouped" in name:
         return "gemm_wgrad_x%d" % N_GROUPED
     if "gemm_bf16_pipe_kernel" in name:
