@@ -295,7 +295,27 @@ __global__ __launch_bounds__(XT) void gemm_f32x3_kernel(GemmF32 g) {
         // the register set just staged is free: re-load it with tile + 3 at once (a K-tile and a half ahead of its use; issued behind
         // the second column block instead, one K-tile ahead, the wait for these loads was 17 % of the launch)
         if constexpr ((X3_DBG & 8) == 0) load(std::integral_constant<int, NXT>{}, tile + 3);
-        __syncthreads();
+        if constexpr ((X3_DBG & 64) == 0) {
+            // issue order of this half: the split and the LDS stores spread over the first 12 MFMAs (so that the stores have landed
+            // when the barrier asks), the global loads over the next four.  (Left to itself the scheduler bunches them: 22 MFMAs in
+            // a row, then the stores right in front of the barrier's lgkmcnt(0).)
+            constexpr int N_DS = (A_KC ? 3 : 6) + (B_KC ? 3 : 6);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);      // eight VALU
+                if ((i * N_DS) / 12 != ((i + 1) * N_DS) / 12) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // one LDS store
+            }
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // one global load
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);      // (MFMAs of this half must not sink behind the barrier, in front of the fragment reads)
+        if constexpr ((X3_DBG & 128) == 0) __syncthreads();
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // nothing moves across (in particular not the next K-tile's split, plain VALU work on the register set whose loads were
         // issued last: the wait for those loads would come up here with it)
         __builtin_amdgcn_sched_barrier(0);
