@@ -259,6 +259,7 @@ __global__ __launch_bounds__(XT) void gemm_f32x3_kernel(GemmF32 g) {
             for (int p = 0; p < 3; ++p) bf[SET][nt][p] = x3_frag<B_KC>(cb + OPND + p * PLANE, 2 * wc + nt, lane);
     };
     read_frags(S0{});
+    if constexpr ((X3_DBG & 256) != 0) read_frags(S1{});
 
     // K-tile `tile` (fragments already in register set CUR): the first column block's MFMAs with the split + LDS stores of tile + 1
     // (register set CUR ^ 1 -> the other LDS buffer) issued between them; the barrier; the fragment reads of tile + 1; the second
@@ -267,23 +268,27 @@ __global__ __launch_bounds__(XT) void gemm_f32x3_kernel(GemmF32 g) {
     auto ktile = [&](int tile, auto cur_tag) {
         constexpr int CUR = decltype(cur_tag)::value, NXT = CUR ^ 1;
         lds_c* nb = smem + NXT * XBUF;
-        auto mma_block = [&](auto nt_tag) {
-            constexpr int nt = decltype(nt_tag)::value;
+        // half h of the K-tile's MFMAs: three of the six plane products (smallest first: 2^-16, 2^-16, 2^-16 | 2^-8, 2^-8, 1
+        // relative to a0 b0) for ALL eight accumulator tiles, product by product - eight independent accumulators between two
+        // MFMAs of one chain.  (Split by column block instead - four accumulators x six products each - the launch took the same
+        // time; with every load, store, split, fragment read and the barrier compiled out (X3_DBG 398) the MFMAs + prologue +
+        // epilogue of the 8192 x 1536 x 1536 forward form take 137-143 us either way: 92 us of pure pipe time at the nominal rate.)
+        auto mma_block = [&](auto h_tag) {
+            constexpr int h = decltype(h_tag)::value;
+            constexpr int PB[6] = {0, 1, 2, 0, 1, 0}, PA[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                // smallest products first (2^-16, 2^-16, 2^-16, 2^-8, 2^-8, 1 relative to a0 b0)
-                f32x4 c = acc[mt][nt];
-                if constexpr ((X3_DBG & 1) != 0) {
-                    asm volatile("" ::"v"(bf[CUR][nt][0]), "v"(bf[CUR][nt][1]), "v"(bf[CUR][nt][2]), "v"(af[CUR][mt][0]), "v"(af[CUR][mt][1]), "v"(af[CUR][mt][2]));
-                    continue;
+            for (int q = 3 * h; q < 3 * h + 3; ++q) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        if constexpr ((X3_DBG & 1) != 0) {
+                            asm volatile("" ::"v"(bf[CUR][nt][PB[q]]), "v"(af[CUR][mt][PA[q]]));
+                            continue;
+                        }
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[CUR][nt][PB[q]], af[CUR][mt][PA[q]], acc[mt][nt], 0, 0, 0);
+                    }
                 }
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[CUR][nt][0], af[CUR][mt][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[CUR][nt][1], af[CUR][mt][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[CUR][nt][2], af[CUR][mt][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[CUR][nt][0], af[CUR][mt][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[CUR][nt][1], af[CUR][mt][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[CUR][nt][0], af[CUR][mt][0], c, 0, 0, 0);
-                acc[mt][nt] = c;
             }
         };
         mma_block(std::integral_constant<int, 0>{});
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(XT) void gemm_f32x3_kernel(GemmF32 g) {
         // nothing moves across (in particular not the next K-tile's split, plain VALU work on the register set whose loads were
         // issued last: the wait for those loads would come up here with it)
         __builtin_amdgcn_sched_barrier(0);
-        read_frags(std::integral_constant<int, NXT>{});
+        if constexpr ((X3_DBG & 256) == 0) read_frags(std::integral_constant<int, NXT>{});
         __builtin_amdgcn_sched_barrier(0);      // (the scheduler sinks the reads below the MFMAs otherwise: fewer live registers)
         mma_block(std::integral_constant<int, 1>{});
         __builtin_amdgcn_sched_barrier(0);
