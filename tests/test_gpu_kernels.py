@@ -601,6 +601,46 @@ def test_ranking_loss_batched_gemm_matches_oracle_and_item_kernel():
     assert 0.2 * B < ref < 0.8 * B                                                       # (random predictions rank mid-field)
 
 
+def test_ranking_loss_batched_at_headline_width_runs_on_the_bf16_plane_gemm(hip, f32_gemm_mode):
+    """The validation rank metric at the headline embedding width (3 x 512, 3072 validation rows of batch 3072, chunks of 1536
+    columns): its similarity GEMMs (24 x 12 tiles, K = 512, the row count of each slot's group read on the DEVICE: GemmF32::m_dev) are
+    large enough for gemm_f32x3.hip - the one caller that hands it a device-side row count.  Against the wave-per-item kernel
+    (RankingLoss.get, one similarity at a time in fp32); near-ties may flip a handful of comparisons."""
+    from codae.tool import RankingLoss
+    S, E, N, V, B = 3, 512, 4000, 3072, 3072
+    g = torch.Generator().manual_seed(5)
+
+    class DS:
+        nb_predictor, nb_used_category, embedding_size = S * E, S, E
+        data_per_category = {c: torch.randn(N, E, generator=g) for c in range(S)}
+    table = torch.ones(S, S * E, dtype=torch.uint8)
+    for c in range(S):
+        table[c, c * E:(c + 1) * E] = 0
+
+    class Corr:
+        mask_table_u8 = table.to(dev())
+        mask_to_use_i32 = torch.randint(0, S, (N, 1), generator=g, dtype=torch.int32).to(dev())
+    val = torch.randperm(N, generator=g)[:V].tolist()
+    rl = RankingLoss(DS(), val, device=dev())
+    idx = torch.tensor(val[:B], dtype=torch.int32)
+    pred = torch.randn(B, S * E, generator=g)
+    fmask = table[Corr.mask_to_use_i32.cpu()[idx.long(), 0].long()].float()
+    sub = list(range(0, B, 8))                                   # the item kernel on every 8th sample is reference enough
+    ref = rl.get(pred[sub].to(dev()), fmask[sub].to(dev()), idx[sub].tolist())
+    rl.add(pred[sub].to(dev()), idx[sub].to(dev()), Corr, run=0, chunk=1536)
+    small = rl.total()
+    assert abs(small - ref) <= 2.0 * len(sub) / (V - 1) * 1e-2 + 1e-6 * abs(ref), (small, ref)
+    rl.add(pred.to(dev()), idx.to(dev()), Corr, run=0, chunk=1536)          # the whole batch: 24 x 12 tiles per slot -> the plane kernel
+    got = rl.total()
+    f32_gemm_mode("native")                                                  # the same launches on the fp32-MFMA kernel
+    rl.add(pred.to(dev()), idx.to(dev()), Corr, run=0, chunk=1536)
+    native = rl.total()
+    assert abs(got - native) <= 20.0 / (V - 1), (got, native)               # a flipped near-tie moves the total by 1 / (V - 1)
+    # every 8th sample is an unbiased sample of the batch: the two per-sample means agree to a few percent
+    assert abs(got / B - ref / len(sub)) <= 0.05 * ref / len(sub), (got / B, ref / len(sub))
+    assert 0.2 * B < got < 0.8 * B
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("rows,cols", [(64, 64), (8, 8), (72, 200), (1536, 1536), (512, 16), (24, 1000)])
 def test_transpose_bf16(rows, cols):
