@@ -125,6 +125,15 @@ int gemm_f32x3(const GemmF32& g, hipStream_t s);      // gemm_f32x3.hip: the sam
 bool gemm_f32x3_takes(const GemmF32& g);              // its shape / alignment conditions (everything else stays on gemm_f32_kernel)
 inline int gemm_f32_colsum_rows(int M) { return (M + 63) / 64; }
 
+// several independent exact-fp32 GEMMs in one launch of the bf16-plane kernel (gemm_f32x3.hip): the fp32 engine's weight gradients
+constexpr int CODAE_GROUP_MAX = 16;
+struct GemmF32Group {
+    int n;
+    GemmF32 g[CODAE_GROUP_MAX];
+    int wg_begin[CODAE_GROUP_MAX + 1];     // prefix sum of workgroups per GEMM (filled by the launcher)
+};
+int gemm_f32x3_grouped(GemmF32Group& grp, hipStream_t s);
+
 // ---- bf16 MFMA GEMM (gemm_bf16.hip) ----------------------------------------
 enum { OP_KC = 0,  // operand stored [rows][k] (k contiguous)
        OP_KS = 1   // operand stored [k][rows] (rows contiguous; transposed LDS reads)
@@ -179,7 +188,6 @@ int gemm_bf16_pipe(const GemmBf16& g, int cfg, hipStream_t s);   // gemm_bf16_pi
 
 // several independent GEMMs (here: the weight gradients of every layer of a narrow stack) in ONE launch; tile
 // configuration 128 x 128 for all of them
-constexpr int CODAE_GROUP_MAX = 16;
 struct GemmBf16Group {
     int n;
     GemmBf16 g[CODAE_GROUP_MAX];

@@ -414,6 +414,20 @@ int run_wgrad_grouped(const codae_engine* e, const codae_buffers* b, int rows, b
 // 0: per-layer weight gradients; 1: one grouped launch of the pipelined 256 x 192 tile; 2: one grouped launch of the one-barrier
 // kernel on 128 x 128 / 64 x 128 / 64 x 64 tiles (run_wgrad_grouped: stacks too narrow to fill the chip with the big tile)
 int defer_wgrad_mode(const codae_engine* e, int rows) {
+    if (e->prec == CODAE_PREC_F32) {
+        // 3: the exact-fp32 engine on the bf16-plane GEMMs - every weight gradient in one launch of gemm_f32x3_grouped_kernel, K unsplit
+        // (what mode 1 is to the bf16 engine: per layer it is 144 tiles, split 7 ways into fp32 slabs and reduced: 0.2 ms of reduce
+        // launches per C3 step and a prologue / epilogue per 37 K-tiles)
+        if (env().f32_gemm == 1 || e->cfg.no_defer_wgrad || e->cfg.single_stream || e->L > CODAE_GROUP_MAX || e->n_dact <= e->L || rows < 256 ||
+            rows % 32 != 0)
+            return 0;
+        int total = 0;
+        for (int l = 0; l < e->L; ++l) {
+            if (e->in[l] % 4 != 0 || e->out[l] % 4 != 0) return 0;
+            total += ((e->out[l] + 127) / 128) * ((e->in[l] + 127) / 128);
+        }
+        return total >= 256 ? 3 : 0;
+    }
     if (e->prec != CODAE_PREC_BF16 || e->cfg.no_defer_wgrad || e->cfg.single_stream || e->L > CODAE_GROUP_MAX || e->n_dact <= e->L || rows < 64)
         return 0;
     int total = 0, total_small = 0;
@@ -426,6 +440,22 @@ int defer_wgrad_mode(const codae_engine* e, int rows) {
     //  the 4 x 8 tile order of the pipelined kernel the grouped launch wins there too: 29.5 against 30.2)
     if (total >= 200) return 1;
     return total_small >= 128 ? 2 : 0;
+}
+
+int run_wgrad_deferred_f32(const codae_engine* e, const codae_buffers* b, int rows, hipStream_t s) {
+    GemmF32Group grp{};
+    grp.n = 0;
+    for (int l = e->L - 1; l >= 0; --l) {            // (backward order: the layers whose operands were touched last come first)
+        GemmF32& g = grp.g[grp.n++];
+        const int N = e->out[l], K = e->in[l];
+        g.A = reinterpret_cast<const float*>(dact_ptr(e, b, l)); g.a_rs = 1; g.a_ks = N;
+        g.B = reinterpret_cast<const float*>(act_ptr(e, b, l)); g.b_rs = 1; g.b_ks = K;
+        g.C = b->grads + e->w_off[l]; g.ldc = K;
+        g.M = N; g.N = K; g.K = rows; g.split_k = 1;
+    }
+    ProfScope prof(e, CODAE_K_GEMM_WGRAD, s);
+    prof.counts_as(grp.n);
+    return gemm_f32x3_grouped(grp, s);
 }
 
 int run_wgrad_deferred(const codae_engine* e, const codae_buffers* b, int rows, hipStream_t s) {
@@ -687,7 +717,8 @@ int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi
             rc = run_dgrad(h, b, l, rows, nullptr, s);
             if (rc) return rc;
         }
-        rc = defer == 1 ? run_wgrad_deferred(h, b, rows, s) : run_wgrad_grouped(h, b, rows, h->norm_in_backward, s);
+        rc = defer == 3 ? run_wgrad_deferred_f32(h, b, rows, s)
+                        : (defer == 1 ? run_wgrad_deferred(h, b, rows, s) : run_wgrad_grouped(h, b, rows, h->norm_in_backward, s));
         if (rc) return rc;
         return finish_bias(h, b, s, h->norm_in_backward);
     }

@@ -172,29 +172,30 @@ __device__ __forceinline__ bf16x8 x3_frag(const lds_c* plane, int tile16, int la
     }
 }
 
+// tile id -> (tile_m, tile_n): ids walk the output in panels of 4 row tiles (down the panel, then the next column), as gemm_f32.hip
+__device__ __forceinline__ void x3_tile_of(int id, int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
+    constexpr int GROUP_M = 4;
+    const int grp = id / (GROUP_M * tiles_n);
+    const int tm0 = grp * GROUP_M;
+    const int gsz = tiles_m - tm0 < GROUP_M ? tiles_m - tm0 : GROUP_M;
+    const int within = id - grp * (GROUP_M * tiles_n);
+    tile_n = within / gsz;
+    tile_m = tm0 + (within - tile_n * gsz);
+}
+// workgroup b of a launch runs on XCD b % 8: give each XCD a contiguous eighth of the ids
+__device__ __forceinline__ int x3_xcd_remap(int id, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+}
+
+// one output tile (split-K range z of it) of one GEMM: the whole kernel body, shared by the plain kernel and the grouped one
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(XT) void gemm_f32x3_kernel(GemmF32 g) {
-    __shared__ __attribute__((aligned(16))) char smem_raw[2 * XBUF];
+__device__ __forceinline__ void x3_tile(GemmF32 g, int tile_m, int tile_n, int z, char* smem_raw) {
     lds_c* smem = (lds_c*)smem_raw;
 
     const int t = threadIdx.x;
     const int lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = w >> 2, wc = w & 3;          // 2 x 4 waves, 64 x 32 outputs each
-    // XCD-aware tile map, as gemm_f32.hip
-    int tile_m, tile_n;
-    {
-        const int tiles_n = gridDim.x, tiles_m = gridDim.y, nwg = tiles_n * tiles_m;
-        int id = blockIdx.y * tiles_n + blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-        constexpr int GROUP_M = 4;
-        const int grp = id / (GROUP_M * tiles_n);
-        const int tm0 = grp * GROUP_M;
-        const int gsz = tiles_m - tm0 < GROUP_M ? tiles_m - tm0 : GROUP_M;
-        const int within = id - grp * (GROUP_M * tiles_n);
-        tile_n = within / gsz;
-        tile_m = tm0 + (within - tile_n * gsz);
-    }
     const int i0 = tile_m * XM, j0 = tile_n * XN;
     const int m_alloc = g.M;            // loads are clamped to the rows that EXIST; a device-side row count only trims the stores
     if (g.m_dev != nullptr) {
@@ -212,10 +213,10 @@ __global__ __launch_bounds__(XT) void gemm_f32x3_kernel(GemmF32 g) {
     int k_begin = 0, k_end = g.K;
     if (g.split_k > 1) {
         const int kt = (g.K + XK - 1) / XK;
-        k_begin = (int)((int64_t)kt * blockIdx.z / g.split_k) * XK;
-        k_end = (int)((int64_t)kt * (blockIdx.z + 1) / g.split_k) * XK;
+        k_begin = (int)((int64_t)kt * z / g.split_k) * XK;
+        k_end = (int)((int64_t)kt * (z + 1) / g.split_k) * XK;
         if (k_end > g.K) k_end = g.K;
-        g.C += (int64_t)blockIdx.z * g.M * g.ldc;
+        g.C += (int64_t)z * g.M * g.ldc;
     }
     const int nk = (k_end - k_begin + XK - 1) / XK;
 
@@ -398,6 +399,30 @@ __global__ __launch_bounds__(XT) void gemm_f32x3_kernel(GemmF32 g) {
     }
 }
 
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(XT) void gemm_f32x3_kernel(GemmF32 g) {
+    __shared__ __attribute__((aligned(16))) char smem_raw[2 * XBUF];
+    const int tiles_n = gridDim.x, tiles_m = gridDim.y;
+    int tile_m, tile_n;
+    x3_tile_of(x3_xcd_remap(blockIdx.y * tiles_n + blockIdx.x, tiles_n * tiles_m), tiles_m, tiles_n, tile_m, tile_n);
+    x3_tile<A_KC, B_KC>(g, tile_m, tile_n, blockIdx.z, smem_raw);
+}
+
+// several GEMMs of the row-contiguous x row-contiguous form (the weight gradients of every layer of the stack: dW_l = dA_l^T act_l) in
+// ONE launch, each with its whole K (the batch) unsplit: no slabs, no reduce pass, one prologue / epilogue per 256 K-tiles
+// instead of per 37.  The XCD remap runs over the whole launch, so an XCD's workgroups work on neighbouring tiles of one GEMM.
+__global__ __launch_bounds__(XT) void gemm_f32x3_grouped_kernel(GemmF32Group grp) {
+    __shared__ __attribute__((aligned(16))) char smem_raw[2 * XBUF];
+    const int id = x3_xcd_remap(blockIdx.x, gridDim.x);
+    int j = 0;
+    while (j + 1 < grp.n && id >= grp.wg_begin[j + 1]) ++j;
+    const GemmF32& g = grp.g[j];
+    const int tiles_m = (g.M + XM - 1) / XM, tiles_n = (g.N + XN - 1) / XN;
+    int tile_m, tile_n;
+    x3_tile_of(id - grp.wg_begin[j], tiles_m, tiles_n, tile_m, tile_n);
+    x3_tile<false, false>(g, tile_m, tile_n, 0, smem_raw);
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -430,6 +455,23 @@ int gemm_f32x3(const GemmF32& g, hipStream_t s) {
         hipLaunchKernelGGL((gemm_f32x3_kernel<false, true>), grid, dim3(XT), 0, s, g);
     else
         hipLaunchKernelGGL((gemm_f32x3_kernel<false, false>), grid, dim3(XT), 0, s, g);
+    CODAE_LAUNCH_CHECK();
+    return CODAE_OK;
+}
+
+int gemm_f32x3_grouped(GemmF32Group& grp, hipStream_t s) {
+    CODAE_REQUIRE(grp.n >= 1 && grp.n <= CODAE_GROUP_MAX, "gemm_f32x3_grouped: %d GEMMs", grp.n);
+    int total = 0;
+    for (int j = 0; j < grp.n; ++j) {
+        const GemmF32& g = grp.g[j];
+        CODAE_REQUIRE(gemm_f32x3_takes(g) && g.a_rs == 1 && g.b_rs == 1 && g.split_k <= 1 && g.m_dev == nullptr && g.bias == nullptr && !g.relu &&
+                          g.relu_src == nullptr && g.colsum_part == nullptr,
+                      "gemm_f32x3_grouped: GEMM %d (M=%d N=%d K=%d) is not a plain row-contiguous x row-contiguous product", j, g.M, g.N, g.K);
+        grp.wg_begin[j] = total;
+        total += ((g.M + XM - 1) / XM) * ((g.N + XN - 1) / XN);
+    }
+    grp.wg_begin[grp.n] = total;
+    hipLaunchKernelGGL(gemm_f32x3_grouped_kernel, dim3(total), dim3(XT), 0, s, grp);
     CODAE_LAUNCH_CHECK();
     return CODAE_OK;
 }
