@@ -22,6 +22,8 @@ N_GROUPED = int(sys.argv[5]) if len(sys.argv) > 5 else 10      # GEMMs inside on
 
 
 def classify(name):
+    if "gemm_f32x3_grouped" in name:
+        return "gemm_wgrad_x%d" % N_GROUPED       # (fp32 engine: every layer's weight gradient in one launch of the bf16-plane kernel)
     if "gemm_f32x3_kernel" in name:        # fp32 products from three bf16 planes per operand: <A k-contiguous, B k-contiguous>
         a = name[name.index("<") + 1:name.index(">")].replace(" ", "").split(",") if "<" in name else ["?", "?"]
         return {("true", "true"): "gemm_f32x3_fwd", ("true", "false"): "gemm_f32x3_dgrad", ("false", "false"): "gemm_f32x3_wgrad"}.get(tuple(a[:2]), "gemm_f32x3")
