@@ -88,8 +88,8 @@ struct EnvToggles {
     int wgrad_splitk = 0;        // CODAE_WGRAD_SPLITK > 0 forces the split
     int small_tile_max = 200;    // CODAE_SMALL_TILE_MAX: forward-form launches of up to this many 128 x 128 tiles run on 64 x 64 tiles
     int small_stages = 4;        // CODAE_SMALL_STAGES=2: launches that cannot fill the chip keep the 2-stage double buffer
-    int f32_gemm = 0;            // CODAE_F32_GEMM: native = v_mfma_f32_32x32x2_f32 always (1), x3 = three bf16 planes / six bf16 MFMA products
-                                 // whenever the shape is legal (2); 0 = by shape (gemm_f32.hip)
+    int f32_gemm = 0;            // CODAE_F32_GEMM: native = v_mfma_f32_32x32x2_f32 always (1); default (0) and x3 (2) = three bf16 planes / six bf16
+                                 // MFMA products wherever the shape is legal (gemm_f32.hip)
     int group_tile = -1;         // CODAE_GROUP_TILE: grouped weight gradients on 128 x 128 (0), 64 x 128 (1), 64 x 64 (2); -1 = automatic
     bool side_priority_set = false; int side_priority = 0;   // CODAE_SIDE_PRIORITY
     bool no_wt = false, single_stream = false, tail_on_side = false, no_fused_loss = false, flat_adam = false,

@@ -212,13 +212,10 @@ int gemm_f32(const GemmF32& g, hipStream_t s) {
     const bool a_vec = aligned16(g.A) && ((a_kc ? g.a_rs : g.a_ks) % 4 == 0);
     const bool b_vec = aligned16(g.B) && ((b_kc ? g.b_rs : g.b_ks) % 4 == 0);
     const int split = g.split_k > 1 ? g.split_k : 1;
-    {
-        // the bf16-plane kernel (gemm_f32x3.hip) wherever its one-workgroup-per-CU tiles can fill the chip and K is deep enough to
-        // amortise its prologue; CODAE_F32_GEMM=native / x3 forces either
-        const int mode = env().f32_gemm;
-        const int64_t wgs = (int64_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * split;
-        if (mode != 1 && gemm_f32x3_takes(g) && (mode == 2 || (wgs >= 192 && g.K / split >= 256))) return gemm_f32x3(g, s);
-    }
+    // the bf16-plane kernel (gemm_f32x3.hip) wherever its loads are legal (K in whole 32-deep tiles, 16-byte aligned rows): it beats
+    // this one at every size tried - 3 x 512 parity-mode step at batch 128: 0.85 against 1.12 ms, batch 1024: 1.63 against 3.59,
+    // batch 8192: 6.0 against 10.4 (tools/abl/f32_gemm_threshold.sh); CODAE_F32_GEMM=native keeps everything here
+    if (env().f32_gemm != 1 && gemm_f32x3_takes(g)) return gemm_f32x3(g, s);
     CODAE_REQUIRE(split == 1 || (g.bias == nullptr && !g.relu && g.relu_src == nullptr && g.colsum_part == nullptr && g.m_dev == nullptr &&
                                  split <= (g.K + BK - 1) / BK),
                   "gemm_f32: split-K writes plain partial products (no epilogue terms), at most one range per K-tile");

@@ -392,10 +392,89 @@ def _oracle_vs_engine(precision, S, E, B, steps, tol):
 
 
 def test_fused_f32_vs_oracle_3x128_batch1024():
-    tr, orc = _oracle_vs_engine("f32", 3, 128, 1024, 3, 1e-3)
+    """Three Adam steps (lr 1e-3) of the fp32 engine against the fp32 oracle: loss, gradient norm and the partial metric sum of
+    every step to 1e-3 (in _oracle_vs_engine); the updated parameters at rtol 1e-3 / atol 1e-5 - for all but the elements whose
+    gradient sits within fp32 rounding of zero.  Adam's first steps move EVERY element by lr in the direction of the sign of
+    g + wd w, so two fp32 evaluations that disagree on such a sign end 2 lr apart on that element.  The engine's fp32-MFMA GEMMs
+    round like numpy's sgemm and agree with the oracle on every one of the 1.47 M elements (CODAE_F32_GEMM=native: 0 outside,
+    largest difference 3e-7); its default GEMMs (three bf16 planes per operand, gemm_f32x3.hip) are CLOSER TO THE TRUTH than the
+    oracle - against a float64 evaluation of the first step the oracle gets 74 signs wrong, these GEMMs none
+    (test_f32_first_step_gradients_against_float64 below: sgemm-style fp32 puts two pre-activations that sit within an ulp of
+    zero on the other side of the ReLU than float64 does, the plane GEMMs' pre-activations are accurate enough to take
+    float64's side) - and so land on the other side of the oracle on 0.4 % of the elements.
+    Bound: at least 99 % of the elements inside rtol 1e-3 / atol 1e-5, every element inside 2 lr per step."""
+    steps, lr = 3, 1e-3
+    tr, orc = _oracle_vs_engine("f32", 3, 128, 1024, steps, 1e-3)
+    outside = total = 0
     for l, (w, b) in enumerate(orc.params):
-        assert close(tr.engine.weight(l).cpu().numpy(), w)
-        assert close(tr.engine.bias(l).cpu().numpy(), b)
+        got = tr.engine.weight(l).cpu().numpy()
+        d = np.abs(got.astype(np.float64) - w)
+        outside += int((d > 1e-5 + 1e-3 * np.abs(w)).sum()); total += w.size
+        assert d.max() <= 2 * lr * steps + 1e-5, (l, d.max())
+        assert close(tr.engine.bias(l).cpu().numpy(), b, atol=2 * lr * steps + 1e-5)
+    assert outside <= 0.01 * total, (outside, total)
+
+
+def test_f32_first_step_gradients_against_float64(monkeypatch):
+    """The same stack's first-step weight gradients against a float64 evaluation of the step (torch on the GPU), for the numpy
+    fp32 oracle and for the fp32 engine on both of its GEMM kernels: relative L2 over all weight gradients and the number of
+    elements of g + wd w with the wrong sign.  Measured: oracle 2.6e-4 / 74 wrong signs of 1 474 560; engine on the fp32-MFMA GEMMs
+    the same 2.6e-4 / 74 (it reproduces numpy's rounding); engine on the bf16-plane GEMMs 3.7e-7 / 0.  The default engine must be at
+    least as close to float64 as the oracle is, in both measures, and within 1e-5 outright."""
+    from codae import hip as H
+    from codae.train import HipEmbeddingTrainer
+    from oracle import dae_oracle as O
+    S, E, B = 3, 128, 1024
+    io = S * E
+    rng = np.random.default_rng(42)
+    N = 4 * B
+    data = rng.random((N, io), dtype=np.float32)
+    data = data / (data.max() - data.min())
+    sched = O.layer_schedule(io, io, 4, 4, False, "embedding")
+    params = O.init_params(sched, rng)
+    bm, nmr, _ = O.corrupter_tables([{"size": E, "position": s * E} for s in range(S)], 1)
+    mtu = np.stack([rng.permutation(S) for _ in range(N)])
+    idx = rng.permutation(N)[:B]
+    _, fmask = O.get_masks(bm, nmr, mtu, 1, idx, 0)
+    wd = 1e-4
+    x = torch.tensor(data[idx], dtype=torch.float64, device=DEV)
+    h = x * torch.tensor(fmask, dtype=torch.float64, device=DEV)
+    Ws = [torch.tensor(w, dtype=torch.float64, device=DEV, requires_grad=True) for w, _ in params]
+    bs = [torch.tensor(b, dtype=torch.float64, device=DEV, requires_grad=True) for _, b in params]
+    for l, (_, _, relu) in enumerate(sched):
+        h = h @ Ws[l].T + bs[l]
+        if relu:
+            h = torch.relu(h)
+    ((h - x) ** 2).mean().backward()
+    truth = [W.grad.cpu().numpy() for W in Ws]
+
+    def distance(grads):
+        wrong, num, den = 0, 0.0, 0.0
+        for l, g in enumerate(grads):
+            ga = g.astype(np.float64) + wd * params[l][0]
+            ta = truth[l] + wd * params[l][0]
+            wrong += int((np.sign(ga) != np.sign(ta)).sum())
+            num += float(((g - truth[l]) ** 2).sum()); den += float((truth[l] ** 2).sum())
+        return (num / den) ** 0.5, wrong
+    orc = O.EmbeddingTrainer(params, [r for _, _, r in sched], 1e-3, wd)
+    orc.step(data[idx], fmask)
+    o_rel, o_wrong = distance([gw for gw, _ in orc.last_grads])
+    res = {}
+    for mode in ("native", "x3"):
+        monkeypatch.setenv("CODAE_F32_GEMM", mode)
+        H.check(H.lib().codae_reload_env())
+        tr = HipEmbeddingTrainer(sched, torch.tensor(data), torch.tensor(bm).to(torch.uint8), torch.tensor(mtu).to(torch.int32), 1e-3, wd, 1.0,
+                                 max_batch=B, precision="f32", device=DEV)
+        tr.load_params(params)
+        tr.train_batch(torch.tensor(idx, dtype=torch.int32, device=DEV), run=0)
+        res[mode] = distance([tr.engine.weight_grad(l).cpu().numpy() for l in range(tr.engine.L)])
+        del tr
+    monkeypatch.delenv("CODAE_F32_GEMM")
+    H.check(H.lib().codae_reload_env())
+    print("first-step weight gradients vs float64 (rel L2, wrong signs): oracle %.3g / %d, fp32-MFMA GEMMs %.3g / %d, bf16-plane GEMMs %.3g / %d"
+          % (o_rel, o_wrong, res["native"][0], res["native"][1], res["x3"][0], res["x3"][1]))
+    assert res["native"][0] <= 1e-3 and res["native"][1] <= 2 * o_wrong + 10, (res, o_rel, o_wrong)
+    assert res["x3"][0] <= min(1e-5, o_rel) and res["x3"][1] <= o_wrong, (res, o_rel, o_wrong)
 
 
 @pytest.mark.parametrize("group_tile", ["auto", "0", "1", "2"])
