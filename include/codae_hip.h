@@ -54,7 +54,10 @@ enum {
 
 /* arithmetic of the GEMM chain */
 enum {
-    CODAE_PREC_F32 = 0,  /* parity mode: fp32 operands, v_mfma_f32_32x32x2_f32 (exact fp32 fma chain) */
+    CODAE_PREC_F32 = 0,  /* parity mode: fp32 operands and fp32 accumulation; products formed from three bf16 planes per operand
+                          * (gemm_f32x3.hip: six v_mfma_f32_16x16x32_bf16 per fp32 product, closer to float64 than an fp32 fma chain)
+                          * wherever rows are 16-byte aligned and K is in whole 32-deep tiles, v_mfma_f32_32x32x2_f32 elsewhere and
+                          * everywhere under CODAE_F32_GEMM=native */
     CODAE_PREC_BF16 = 1  /* throughput mode: bf16 operands, fp32 accumulate, v_mfma_f32_16x16x32_bf16; every layer width a
                           * multiple of 8 (16-byte rows; the activation buffers pad their rows to multiples of 64 themselves);
                           * codae_create returns CODAE_E_UNSUPPORTED otherwise (the caller falls back to CODAE_PREC_F32) */
@@ -344,7 +347,7 @@ int codae_ranking_loss(const float* pred, const float* fmask, const int32_t* idx
 
 /* RankingLoss.get for a whole validation batch as GEMMs (metering.py:46-79), nothing through the host:
  * blanked slot of sample b from mask_table[id_b] with id_b = mask_id[b] or mask_to_use[row_idx[b] * nb_run + run] (the
- * Corrupter's device tables, as codae_batch); similarities pred[:, slot] . inv_val^T by the exact-fp32 MFMA GEMM, chunk
+ * Corrupter's device tables, as codae_batch); similarities pred[:, slot] . inv_val^T by the fp32 GEMM of the parity engine, chunk
  * validation rows at a time; *out += sum_b 1 - rank_b / (n_val - 1) (accumulates over the batches of an epoch).
  * inv_val [n_slots][n_val][E] = codae_gather_inventory_rows(inventory, val_idx), inv_val_norm its row norms;
  * val_pos [n_obs]: position of an observation in val_idx or -1 (a sample's own validation row is never counted: the
@@ -366,7 +369,7 @@ int codae_gather_inventory_rows(const float* inventory, int64_t n_obs, int32_t E
                                 int32_t n_val, float* dst, void* stream);
 
 /* ---- GEMM primitives (exported for kernel-level parity tests / benchmarks) - */
-/* y[M][N] = act(x[M][K] . W[N][K]^T + b[N]), fp32, exact-fp32 MFMA */
+/* y[M][N] = act(x[M][K] . W[N][K]^T + b[N]), fp32 in / fp32 out (the parity engine's GEMM: CODAE_PREC_F32 above) */
 int codae_linear_f32(const float* x, const float* W, const float* b, float* y, int32_t M, int32_t N,
                      int32_t K, int32_t relu, void* stream);
 /* dx[M][K] = (dy[M][N] . W[N][K]) * [relu_src > 0]   (relu_src [M][K] or NULL) */

@@ -110,7 +110,7 @@ class _HipDenoisingAutoencoder(torch.nn.Module):
                 eng = DaeEngine(self._schedule, cap, want_prec, dev, with_optimizer_state=False)
             except HipError:
                 if want_prec == precision_code("bf16"):
-                    # widths the bf16 tiles cannot take (e.g. abalone's 11): exact-fp32 kernels instead
+                    # widths the bf16 tiles cannot take (e.g. abalone's 11): fp32 kernels instead
                     eng = DaeEngine(self._schedule, cap, "f32", dev, with_optimizer_state=False)
                     self.precision = "f32"
                 else:
