@@ -23,9 +23,14 @@ __device__ __forceinline__ void wait_vmcnt() {
 // (KEEP of them, compiler-visible ds_read_b128 only) may stay in flight across it.
 template <int KEEP = 0>
 __device__ __forceinline__ void phase_barrier() {
+    // Nothing is scheduled across a phase boundary.  Left free, the compiler moved MFMAs across the barriers until the phases held
+    // 3 to 22 of them instead of 12 each, and all eight waves starve the matrix pipe in the same thin phases (whole C3 step
+    // 1.197 -> 1.190 ms with the phases pinned, -> 1.182 with the issue order inside them fixed as well: gemm_bf16_pipe.hip).
+    __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(KEEP) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // ---- half-tile images ------------------------------------------------------------------------
