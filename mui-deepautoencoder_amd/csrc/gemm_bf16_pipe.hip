@@ -254,7 +254,8 @@ __device__ __forceinline__ void gemm_bf16_pipe_tile(const GemmBf16& g, int tiles
     // one per MFMA, then this wave's LDS-DMA pieces one per MFMA, then the rest of the 12 MFMAs.  Measured against the
     // compiler's own order with the phases pinned (phase_barrier), whole C3 step on one box, three alternating runs each:
     // 1.190 -> 1.182 ms (forward 35.4 -> 34.9 us, data gradient 38.3 -> 37.7, fused loss 54.7 -> 52.4); DMA pieces first: 1.197;
-    // reads and DMA pieces paired behind the first six MFMAs: 1.191; all reads at once behind the first MFMA: 1.206.
+    // reads and DMA pieces paired behind the first six MFMAs: 1.191; all reads at once behind the first MFMA: 1.206; three more
+    // interleavings (reads then DMA back to back; read / DMA alternating over all twelve; two MFMAs up front): within noise of this one.
     auto phase_order = [&](auto nread_tag, auto ndma_tag) {
         if constexpr (A_MODE == OP_KC && B_MODE == OP_KC) {
             constexpr int NREAD = decltype(nread_tag)::value, NDMA = decltype(ndma_tag)::value;
