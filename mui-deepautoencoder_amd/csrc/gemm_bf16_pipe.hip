@@ -256,6 +256,9 @@ __device__ __forceinline__ void gemm_bf16_pipe_tile(const GemmBf16& g, int tiles
     // 1.190 -> 1.182 ms (forward 35.4 -> 34.9 us, data gradient 38.3 -> 37.7, fused loss 54.7 -> 52.4); DMA pieces first: 1.197;
     // reads and DMA pieces paired behind the first six MFMAs: 1.191; all reads at once behind the first MFMA: 1.206; three more
     // interleavings (reads then DMA back to back; read / DMA alternating over all twelve; two MFMAs up front): within noise of this one.
+    // (The k-strided forms' phases laid out by hand with sched_barriers around the asm-issued transposed reads - reads first; two
+    // MFMAs, reads, three MFMAs, DMA, rest; two MFMAs, DMA + reads, rest -: grouped weight gradients 33.1-33.6 us against 32.8-33.1
+    // for the compiler's own interleaving: left alone.)
     auto phase_order = [&](auto nread_tag, auto ndma_tag) {
         if constexpr (A_MODE == OP_KC && B_MODE == OP_KC) {
             constexpr int NREAD = decltype(nread_tag)::value, NDMA = decltype(ndma_tag)::value;
