@@ -402,3 +402,40 @@ def test_shard_batch_skips_batches_smaller_than_the_world():
         c = Corrupter(nb_observation=20, arch=arch, k_max=1, device=torch.device("cpu"))
         tabs.append((c.mask_to_use.clone(), torch.randperm(7)))
     assert torch.equal(tabs[0][0], tabs[1][0]) and torch.equal(tabs[0][1], tabs[1][1])
+
+
+def test_three_bf16_planes_carry_an_fp32_value_and_six_products_carry_its_product():
+    """The arithmetic of gemm_f32x3.hip restated in numpy (no GPU): a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1) with
+    round-to-nearest-even; the differences are exact in fp32; the planes leave out less than 2^-24 |a|; of the nine plane
+    products the six the kernel keeps reproduce a * b to 1.5 * 2^-23 relative, each of them exactly representable in fp32
+    (8 x 8 significant bits).  Integers below 2^24 split exactly."""
+    def bf16(x):                     # round-to-nearest-even to 8 significant bits, kept as float32
+        u = np.asarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+        u = (u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000
+        return u.astype(np.uint32).view(np.float32)
+
+    def planes(x):
+        x = np.asarray(x, dtype=np.float32)
+        p0 = bf16(x)
+        r1 = (x - p0).astype(np.float32)
+        assert np.array_equal(r1.astype(np.float64), x.astype(np.float64) - p0.astype(np.float64))        # exact in fp32
+        p1 = bf16(r1)
+        r2 = (r1 - p1).astype(np.float32)
+        assert np.array_equal(r2.astype(np.float64), r1.astype(np.float64) - p1.astype(np.float64))
+        return p0, p1, bf16(r2)
+    rng = np.random.default_rng(0)
+    a = (rng.standard_normal(200000) * np.exp(rng.uniform(-20, 20, 200000))).astype(np.float32)
+    b = (rng.standard_normal(200000) * np.exp(rng.uniform(-20, 20, 200000))).astype(np.float32)
+    pa, pb = planes(a), planes(b)
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    assert np.all(np.abs(a64 - sum(p.astype(np.float64) for p in pa)) <= 2.0 ** -24 * np.abs(a64))
+    assert np.all(np.abs(pa[1]) <= 2.0 ** -8 * np.abs(a) * 1.01) and np.all(np.abs(pa[2]) <= 2.0 ** -16 * np.abs(a) * 1.01)
+    kept = [(0, 2), (1, 1), (2, 0), (0, 1), (1, 0), (0, 0)]                    # (plane of a, plane of b): i + j <= 2
+    total = np.zeros_like(a64)
+    for i, j in kept:
+        prod64 = pa[i].astype(np.float64) * pb[j].astype(np.float64)
+        assert np.array_equal((pa[i] * pb[j]).astype(np.float64), prod64)       # each kept product is exact in fp32
+        total += prod64
+    assert np.all(np.abs(total - a64 * b64) <= 1.5 * 2.0 ** -23 * np.abs(a64 * b64))
+    ints = rng.integers(-(2 ** 24) + 1, 2 ** 24, 100000).astype(np.float32)
+    assert np.array_equal(sum(p.astype(np.float64) for p in planes(ints)), ints.astype(np.float64))
