@@ -48,8 +48,11 @@ def test_default_bench_line_c3_with_fp32_parity_leg():
     assert rs["bound"] == "mfma" and abs(rs["frac"] - rs["achieved"] / rs["peak"]) < 1e-9 and 0.0 < rs["frac"] < 1.0, line
     f = d["f32_parity"]
     assert f["ms_per_step"] > 0 and f["steps"] == 10 and abs(f["samples_per_s"] - 8192 / (f["ms_per_step"] * 1e-3)) <= 1e-6 * f["samples_per_s"], line
+    assert abs(f["frac"] - f["tflops"] / f["roofline_tflops"]) < 1e-9 and f["roofline_tflops"] in (157.3, 2500.0 / 6.0), line
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1, line
+    # thread pools capped at the container's CPU quota before the timed region (codae/hostcpu.py): the baseline ran on that many
+    assert d["host_cpu_share"] >= 1 and d["host_threads"] <= d["host_cpu_share"] and c["cores"] <= d["host_cpu_share"], line
 
 
 def test_bench_line_c2_takes_the_chain():
