@@ -30,8 +30,10 @@ namespace codae {
 namespace {
 
 constexpr int XM = 128, XN = 128, XK = 32, XT = 512;
-// timing-only ablation builds (make EXTRA=-DX3_DBG=n): 1 no MFMAs, 2 no split arithmetic (planes = raw halves), 4 no LDS stores in
-// the loop, 8 no global loads in the loop, 16 no fragment reads in the loop.  0 in the library that ships.
+// timing-only ablation builds (make EXTRA=-DX3_DBG=n, bits): 1 no MFMAs, 2 no split arithmetic (planes = raw halves), 4 no LDS stores
+// in the loop, 8 no global loads in the loop, 64 the compiler's own issue order in the first half, 128 no workgroup barrier, 256 no
+// fragment reads in the loop.  Wrong results, right instruction mix: what DESIGN.md 5f's breakdown was measured with.  0 in the
+// library that ships.
 #ifndef X3_DBG
 #define X3_DBG 0
 #endif
@@ -106,17 +108,6 @@ __device__ __forceinline__ void x3_load(float (&reg)[8], const float* __restrict
 //   !KC: k-rows 2 (t >> 5), + 1, rows 4 (t & 31) .. + 3 of each: 8 B per plane and k-row into the k-major image (ds_write_b64)
 template <bool KC>
 __device__ __forceinline__ void x3_store(lds_c* opnd, const float (&reg)[8], int t) {
-    if constexpr ((X3_DBG & 32) != 0) {
-        // timing only: the same bytes through ds_write_addtid_b32 (no address VGPR; lane l writes dword l of a 256-B segment at M0 + offset)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            uint32_t a, b, c;
-            split_pair(reg[2 * q], reg[2 * q + 1], a, b, c);
-            asm volatile("s_mov_b32 m0, %3\n\tds_write_addtid_b32 %0 offset:0\n\tds_write_addtid_b32 %1 offset:8192\n\tds_write_addtid_b32 %2 offset:16384"
-                         :: "v"(a), "v"(b), "v"(c), "s"((uint32_t)(uintptr_t)opnd + 256u * (uint32_t)(4 * __builtin_amdgcn_readfirstlane(t >> 6) + q)) : "memory", "m0");
-        }
-        return;
-    }
     if constexpr (KC) {
         const int row = t >> 2;
         lds_c* dst = opnd + row * 64 + (chunk_slot(row, t & 3) << 4);
