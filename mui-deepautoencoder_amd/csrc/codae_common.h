@@ -176,6 +176,10 @@ struct GemmBf16 {
     const void* prefetch; int64_t prefetch_bytes;   // pipelined 256 x 192 kernel only: touched (one 4-B load per 128-B line, spread
                              // over the launch's workgroups) while the epilogue runs - the NEXT launch's weight matrix, which
                              // would otherwise come from HBM under its first K-tiles; null = nothing
+    int coscheduled;         // this launch shares the chip with another stream's kernels (the data-gradient chain beside the per-layer
+                             // weight gradients of the data-parallel / bucketed backward): the pipelined kernel keeps the COMPILER's
+                             // instruction schedule - its pinned, hand-ordered phases (gemm_bf16_halftile.h) win 1.3 % when the launch
+                             // has the chip to itself and lose 7.5 % of the step in that company (tools/abl/ab_dp.sh)
     double* sumsq_slots;     // fp32 output, 128 x 128 tile only: += sum of the stored values' squares, scattered over the
                              // CODAE_S_N_SLOTS clip_grad_norm_ slots (what sumsq_kernel would add in a pass of its own), or null
 };

@@ -102,6 +102,7 @@ struct codae_engine {
     // issued bucket by bucket without joins (codae_step_backward_async) stays ordered
     mutable bool w_pending[CODAE_MAX_DACT] = {};
     mutable bool side_dirty = false;      // side-stream work not yet joined into the caller's stream
+    mutable bool bwd_coscheduled = false; // inside a backward whose weight gradients run beside the data-gradient chain (GemmBf16::coscheduled)
     // single-GPU fused step: the slab reduce of every layer also accumulates sum g^2 (clip_grad_norm_)
     mutable bool norm_in_backward = false;
     mutable bool norm_scalars_zero = false;   // finish_loss of this step zeroed GRAD_SQ + its slots and nothing added since
@@ -589,6 +590,7 @@ int run_dgrad(const codae_engine* e, const codae_buffers* b, int l, int rows, fl
     ProfScope prof(e, CODAE_K_GEMM_DGRAD, s);
     if (e->prec == CODAE_PREC_BF16) {
         GemmBf16 g{};
+        g.coscheduled = e->bwd_coscheduled ? 1 : 0;
         g.A = reinterpret_cast<const bf16_t*>(dact_ptr(e, b, l)); g.lda = e->out_ld[l]; g.a_mode = OP_KC;
         if (b->shadow_wt != nullptr && l >= 1 && !e->cfg.no_wt) {
             // dx[m][k] = sum_n dy[m][n] Wt[k][n]: both operands k-contiguous -> the forward-form kernel
@@ -723,6 +725,11 @@ int backward_range(codae_handle h, const codae_buffers* b, int B, int lo, int hi
         return finish_bias(h, b, s, h->norm_in_backward);
     }
     bool* w_pending = h->w_pending;
+    struct Cosched {                       // (reset on every way out of the function)
+        codae_handle h;
+        ~Cosched() { h->bwd_coscheduled = false; }
+    } cosched_guard{h};
+    h->bwd_coscheduled = dual;
     for (int l = hi - 1; l >= lo; --l) {
         int rc;
         if (!dual) {

@@ -21,16 +21,19 @@ __device__ __forceinline__ void wait_vmcnt() {
 // All but the wave's KEEP youngest LDS reads have returned; then the workgroup barrier.  The LDS-DMA issued after
 // the barrier overwrites a region whose last readers ran TWO phases ago, so the reads of the phase just finished
 // (KEEP of them, compiler-visible ds_read_b128 only) may stay in flight across it.
-template <int KEEP = 0>
+template <int KEEP = 0, bool PIN = false>
 __device__ __forceinline__ void phase_barrier() {
-    // Nothing is scheduled across a phase boundary.  Left free, the compiler moved MFMAs across the barriers until the phases held
-    // 3 to 22 of them instead of 12 each, and all eight waves starve the matrix pipe in the same thin phases (whole C3 step
-    // 1.197 -> 1.190 ms with the phases pinned, -> 1.182 with the issue order inside them fixed as well: gemm_bf16_pipe.hip).
-    __builtin_amdgcn_sched_barrier(0);
+    // PIN (the k-contiguous forms: forward, data gradient, fused loss): nothing is scheduled across the phase boundary.  Left free, the
+    // compiler moved MFMAs across the barriers until the phases held 3 to 22 of them instead of 12 each, and all eight waves starve
+    // the matrix pipe in the same thin phases (whole C3 step 1.197 -> 1.190 ms with the phases pinned, -> 1.182 with the issue order
+    // inside them fixed as well: gemm_bf16_pipe.hip).  The k-strided forms stay free: pinned, the grouped weight gradients lose
+    // 0.3 us each and the split-K weight gradient of the data-parallel backward, which shares the chip with the data-gradient
+    // chain, 10 % (one-rank rehearsal 1.44 -> 1.55 ms/step, tools/abl/ab_dp.sh).
+    if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(KEEP) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
 }
 
 // ---- half-tile images ------------------------------------------------------------------------

@@ -260,7 +260,7 @@ __device__ __forceinline__ void gemm_bf16_pipe_tile(const GemmBf16& g, int tiles
     // MFMAs, reads, three MFMAs, DMA, rest; two MFMAs, DMA + reads, rest -: grouped weight gradients 33.1-33.6 us against 32.8-33.1
     // for the compiler's own interleaving: left alone.)
     auto phase_order = [&](auto nread_tag, auto ndma_tag) {
-        if constexpr (A_MODE == OP_KC && B_MODE == OP_KC) {
+        if constexpr (A_MODE == OP_KC && B_MODE == OP_KC && (DBG & 64) == 0) {
             constexpr int NREAD = decltype(nread_tag)::value, NDMA = decltype(ndma_tag)::value;
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
@@ -275,6 +275,7 @@ __device__ __forceinline__ void gemm_bf16_pipe_tile(const GemmBf16& g, int tiles
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         }
     };
+    constexpr bool PINP = (A_MODE == OP_KC && B_MODE == OP_KC) && (DBG & 64) == 0;      // see phase_barrier; DBG 64: GemmBf16::coscheduled
     using RA = std::integral_constant<int, 2 * TMH>;
     using RB = std::integral_constant<int, 2 * TNH>;
     using DA = std::integral_constant<int, a_loader ? NA : 0>;
@@ -282,7 +283,7 @@ __device__ __forceinline__ void gemm_bf16_pipe_tile(const GemmBf16& g, int tiles
     auto ktile = [&](int t, bf16x8 (&a0)[TMH][2], bf16x8 (&a0n)[TMH][2]) {
         // P1: A0 x B0
         wait_for_a();
-        phase_barrier<KEEP_B>();            // (the previous phase, P4, read a B half)
+        phase_barrier<KEEP_B, PINP>();      // (the previous phase, P4, read a B half)
         if constexpr (A_MODE == OP_KS) settle(a0);
         if constexpr (B_MODE == OP_KS) settle(b0);
         issue_a(t + 2, 0);
@@ -291,7 +292,7 @@ __device__ __forceinline__ void gemm_bf16_pipe_tile(const GemmBf16& g, int tiles
         phase_order(RA{}, DA{});
         // P2: A1 x B0
         wait_for_b();
-        phase_barrier<KEEP_A>();
+        phase_barrier<KEEP_A, PINP>();
         if constexpr (A_MODE == OP_KS) settle(a1);
         issue_b(t + 2, 0);
         read_b(b1, t, 1);
@@ -299,7 +300,7 @@ __device__ __forceinline__ void gemm_bf16_pipe_tile(const GemmBf16& g, int tiles
         phase_order(RB{}, DB{});
         // P3: A1 x B1
         wait_for_a();
-        phase_barrier<KEEP_B>();
+        phase_barrier<KEEP_B, PINP>();
         if constexpr (B_MODE == OP_KS) settle(b1);
         issue_a(t + 2, 1);
         read_a(a0n, t + 1, 0);
@@ -307,7 +308,7 @@ __device__ __forceinline__ void gemm_bf16_pipe_tile(const GemmBf16& g, int tiles
         phase_order(RA{}, DA{});
         // P4: A0 x B1
         wait_for_b();
-        phase_barrier<KEEP_A>();
+        phase_barrier<KEEP_A, PINP>();
         issue_b(t + 2, 1);
         read_b(b0, t + 1, 0);
         mma(a0, b1, 0, 1);
@@ -783,6 +784,12 @@ int launch_pipe(const GemmBf16& g, hipStream_t s) {
     hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, WM, WN, NLB, AM, BMODE, CF, 0, EP>), grid, block, 0, s, g, tiles_n, tiles_m * tiles_n, kt_total)
 #define LAUNCH_BF16(AM, BMODE) do { if (bwd_epi) LAUNCH(AM, BMODE, false, 2); else LAUNCH(AM, BMODE, false, 1); } while (0)
     const bool bwd_epi = g.relu_src != nullptr || g.colsum_part != nullptr;
+    // (the data gradient beside another stream's weight gradients: the same kernel with the compiler's schedule, GemmBf16::coscheduled)
+    if (g.coscheduled && bwd_epi && !g.loss.enabled && g.a_mode == OP_KC && g.b_mode == OP_KC && !g.c_f32) {
+        hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, WM, WN, NLB, OP_KC, OP_KC, false, 64, 2>), grid, block, 0, s, g, tiles_n, tiles_m * tiles_n, kt_total);
+        CODAE_LAUNCH_CHECK();
+        return CODAE_OK;
+    }
     if (g.loss.enabled) {
         if constexpr (WM * WN == 8) LAUNCH(OP_KC, OP_KC, false, 3);
         else { set_error("gemm_bf16: fused loss is built for the 8-wave pipelined tile only"); return CODAE_E_UNSUPPORTED; }
