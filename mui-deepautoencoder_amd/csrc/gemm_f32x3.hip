@@ -7,8 +7,11 @@
 //   a * b = the sum of nine plane products; a1 b2 + a2 b1 + a2 b2 <= 2^-23 |a b| are dropped.  The six that stay are each
 //   EXACT in fp32 (8 x 8 significant bits) and are added by v_mfma_f32_16x16x32_bf16 into fp32 accumulators - the accumulation
 //   the fp32 MFMA of gemm_f32.hip performs, on products that are within 1.5 * 2^-23 (relative, either sign) of the exact ones:
-//   about what a separately rounded fp32 multiply would lose.  Measured against an fp64 product the result is as close as
-//   gemm_f32.hip's (tests/test_gpu_kernels.py); integer-valued operands below 2^24 give bit-exact results.  Non-finite
+//   about what a separately rounded fp32 multiply would lose - and 32 of them share ONE fp32 rounding (the MFMA's k-depth) where an
+//   fp32 fma chain rounds after every product.  Measured against float64: kernel level 10-15 % closer than gemm_f32.hip in every
+//   form (tests/test_gpu_kernels.py); step level all first-step weight gradients of a 10-layer stack within 3.7e-7 where the fp32
+//   fma-chain arithmetic (numpy, gemm_f32.hip) is 2.6e-4 off (tests/test_gpu_parity.py); integer-valued operands below 2^24 give
+//   bit-exact results.  Non-finite
 //   inputs come out as NaN (inf - inf in the split), which the native kernel would have passed on as inf.
 //
 // Why: the bf16 MFMA rate is 16 x the fp32 MFMA rate (2.5 PFLOP/s against 157 TFLOP/s dense), so six bf16 products per fp32
@@ -253,9 +256,9 @@ __device__ __forceinline__ void x3_tile(GemmF32 g, int tile_m, int tile_n, int z
     read_frags(S0{});
     if constexpr ((X3_DBG & 256) != 0) read_frags(S1{});
 
-    // K-tile `tile` (fragments already in register set CUR): the first column block's MFMAs with the split + LDS stores of tile + 1
-    // (register set CUR ^ 1 -> the other LDS buffer) issued between them; the barrier; the fragment reads of tile + 1; the second
-    // column block's MFMAs; the global loads of tile + 3.  One barrier per K-tile: a wave that stores tile + 2 into buffer CUR (next
+    // K-tile `tile` (fragments already in register set CUR): the first half of its MFMAs with the split + LDS stores of tile + 1
+    // (register set CUR ^ 1 -> the other LDS buffer) and the global loads of tile + 3 issued between them; the barrier; the
+    // fragment reads of tile + 1; the second half of the MFMAs.  One barrier per K-tile: a wave that stores tile + 2 into buffer CUR (next
     // K-tile) has passed this one's barrier, which every wave reaches only after its last use of the fragments it read from CUR.
     auto ktile = [&](int tile, auto cur_tag) {
         constexpr int CUR = decltype(cur_tag)::value, NXT = CUR ^ 1;
